@@ -1,0 +1,168 @@
+"""Pin the CPU oracle (oracle/protstruc_oracle.py) to the reference.
+
+Every expected value here was produced by the reference itself
+(tools/make_golden.py, run in the build container) or is an analytic known
+answer from the reference's own tests (tests/test_geometry.py:35-190,
+:246-262 in the reference checkout).  Float outputs must agree to 1e-6 (they
+normally agree bit-for-bit: same ATen / numpy primitives); masks and NaN
+positions must be identical.
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import protstruc_oracle as O
+from tests.conftest import load_golden
+
+TOL = 1e-6
+
+
+def close(got, want, tol=TOL):
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert got.dtype == want.dtype, (got.dtype, want.dtype)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)), "NaN positions differ"
+    ok = torch.isclose(got, want, rtol=0, atol=tol, equal_nan=True)
+    assert ok.all(), f"max abs diff {(got - want).abs().nan_to_num(0).max().item():.3e}"
+
+
+@pytest.mark.parametrize("name", [
+    "g1_dist_b2_n8", "g1_dist_b1_n21", "g1_dist_b2_n6_a25", "g1_dist_floatmask", "g1_dist_nan",
+])
+def test_pairwise_distance_matrix(name):
+    g = load_golden(name)
+    d, m = O.pairwise_distance_matrix(g["xyz"], g["atom_mask"])
+    close(d, g["dist"])
+    assert m.dtype == g["dist_mask"].dtype
+    assert torch.equal(m, g["dist_mask"])
+    d2, m2 = O.pairwise_distance_matrix_chunked(g["xyz"], g["atom_mask"])
+    assert torch.equal(d2.isnan(), d.isnan()) and torch.equal(d2.nan_to_num(0), d.nan_to_num(0))
+    assert torch.equal(m2, m)
+
+
+def test_pairwise_distance_matrix_protein_scale():
+    # at 30 A scale one fp32 ulp is ~4e-6..8e-6: gate at 2 ulp of the value
+    g = load_golden("g1_dist_b1_n12_protein_scale")
+    d, m = O.pairwise_distance_matrix(g["xyz"], g["atom_mask"])
+    ulp = torch.finfo(torch.float32).eps * g["dist"].abs().clamp_min(1.0)
+    assert ((d - g["dist"]).abs() <= 2 * ulp).all()
+    assert torch.equal(m, g["dist_mask"])
+
+
+@pytest.mark.parametrize("name", ["g2_bbdih_chains", "g2_bbdih_padded_nan", "g2_bbdih_default_a25"])
+def test_backbone_dihedrals(name):
+    g = load_golden(name)
+    xyz = g["xyz"]
+    B, N = xyz.shape[:2]
+    if "atom_mask" in g:
+        residue_mask = g["atom_mask"].any(dim=-1)
+        chain_idx = g["chain_idx"]
+    else:
+        residue_mask = torch.ones(B, N, dtype=torch.bool)
+        chain_idx = torch.zeros(B, N)
+    nterm = O.n_terminal_mask(chain_idx, residue_mask)
+    cterm = O.c_terminal_mask(chain_idx, residue_mask)
+    assert nterm.dtype == torch.bool and torch.equal(nterm, g["nterm"])
+    assert cterm.dtype == torch.bool and torch.equal(cterm, g["cterm"])
+    dih, dmask = O.backbone_dihedrals(xyz, chain_idx, residue_mask)
+    close(dih, g["dihedrals"])
+    assert dmask.dtype == torch.bool and torch.equal(dmask, g["dihedral_mask"])
+
+
+def test_pairwise_dihedrals_and_planar_angles():
+    g = load_golden("g3_pairwise_angles")
+    xyz = g["xyz"]
+    S = {"N": 0, "CA": 1, "C": 2, "O": 3, "CB": 4}
+
+    def slots(txt):
+        return [S[t.upper()] for t in txt.split("_") if t]
+
+    n_checked = 0
+    for key, want in g.items():
+        if not (key.startswith("dih_") or key.startswith("ang_")):
+            continue
+        left, right = key[4:].split("__")
+        fn = O.pairwise_dihedrals if key.startswith("dih_") else O.pairwise_planar_angles
+        got = fn(xyz, slots(left), slots(right))
+        close(got, want)
+        n_checked += 1
+    assert n_checked == 8
+    # the reference's exact-zero diagonal (identical operands in the first cross product)
+    omega = O.pairwise_dihedrals(xyz, [1, 4], [1, 4])
+    diag = torch.diagonal(omega, dim1=1, dim2=2)
+    assert (diag == 0).all() and not torch.signbit(diag).any()
+    # planar-angle diagonal is NaN (0/0) when points 2 and 3 coincide
+    phi = O.pairwise_planar_angles(xyz, [1, 4], [4])
+    assert torch.diagonal(phi, dim1=1, dim2=2).isnan().all()
+
+
+def test_frames():
+    g = load_golden("g5_frames")
+    xyz = g["xyz"]
+    close(O.backbone_orientations(xyz), g["rot_default"])
+    close(O.backbone_orientations(xyz, 2, 1, 0), g["rot_C_CA_N"])
+    close(O.backbone_orientations(xyz, 4, 1, 3), g["rot_CB_CA_O"])
+    assert torch.equal(O.backbone_translations(xyz), g["trans_CA"])
+    assert torch.equal(O.backbone_translations(xyz, 0), g["trans_N"])
+    # reference tests/test_geometry.py:246-262: ideal N/CA/C gives the identity frame, exactly
+    ideal = g["ideal_xyz"]
+    rot = O.gram_schmidt(ideal[:, :, 0], ideal[:, :, 1], ideal[:, :, 2])
+    assert torch.equal(rot, g["ideal_rot"])
+    assert (rot == torch.eye(3).expand(2, 10, -1, -1)).all()
+
+
+def test_standardize_roundtrip():
+    g = load_golden("g6_standardize")
+    for k in range(4):
+        xyz, mask = g[f"xyz_{k}"], g[f"atom_mask_{k}"]
+        out, mu, std = O.standardize(xyz, mask)
+        close(mu, g[f"mu_{k}"])
+        close(std, g[f"std_{k}"])
+        close(out, g[f"std_xyz_{k}"])
+        close(O.unstandardize(out, mu, std), g[f"unstd_xyz_{k}"])
+    # batched call == per-structure calls (the semantics the reference intends)
+    xyz = torch.cat([g["xyz_0"], g["xyz_0"].flip(1) * 2.0])
+    mask = torch.cat([g["atom_mask_0"], g["atom_mask_0"].flip(1)])
+    out, mu, std = O.standardize(xyz, mask)
+    for b in range(2):
+        o1, m1, s1 = O.standardize(xyz[b:b + 1], mask[b:b + 1])
+        assert torch.equal(o1[0], out[b]) and torch.equal(m1[0], mu[b]) and torch.equal(s1[0], std[b])
+
+
+def test_diffuse_deterministic_part():
+    g = load_golden("g7_diffuse")
+    got = O.diffuse_xyz(g["xyz"], g["beta"], g["noise"])
+    assert torch.equal(got, g["out"])
+
+
+def test_inter_residue_geometry():
+    g = load_golden("g8_inter_residue_geometry")
+    geo = O.inter_residue_geometry(g["xyz"], g["atom_mask"])
+    assert set(geo) == {"d_ca", "d_ca_mask", "d_cb", "d_cb_mask", "d_no", "d_no_mask", "omega", "theta", "phi"}
+    for k, v in geo.items():
+        if k.endswith("_mask"):
+            assert torch.equal(v, g[k])
+        else:
+            close(v, g[k])
+
+
+def test_primitives_known_answers():
+    g = load_golden("g9_primitives")
+    a, b, c, d, c60 = g["a"], g["b"], g["c"], g["d"], g["c60"]
+    # analytic values asserted by the reference's tests/test_geometry.py:35-190
+    assert torch.allclose(O.angle(a, b, c, to_degree=True), torch.tensor([90.0]))
+    assert torch.allclose(O.angle(a, b, c60, to_degree=True), torch.tensor([60.0]), atol=1e-4)
+    assert torch.allclose(O.dihedral(a, b, c, d, to_degree=True), torch.tensor([-90.0]))
+    assert O.dihedral(a, b, c, d).shape == (1,)
+    assert O.dihedral(a[None], b[None], c[None], d[None]).shape == (1, 1)
+    close(O.angle(a, b, c, to_degree=True), g["angle_abc_deg"])
+    close(O.dihedral(a, b, c, d, to_degree=True), g["dihedral_abcd_deg"], tol=1e-5)
+    assert O.dot(torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4.0, 5.0, 6.0])).item() == 32.0
+    assert math.isclose(O.norm(torch.tensor([1.0, 2.0, 3.0])).item(), math.sqrt(14), rel_tol=1e-6)
+    P = g["P"]
+    close(O.angle(P[0], P[1], P[2]), g["rnd_angle"])
+    close(O.dihedral(P[0], P[1], P[2], P[3]), g["rnd_dihedral"])
+    close(O.dot(P[0], P[1]), g["rnd_dot"])
+    close(O.norm(P[0]), g["rnd_norm"])
+    close(O.unit(P[0]), g["rnd_unit"])
+    close(O.gram_schmidt(P[0], P[1], P[2]), g["rnd_frame"])
