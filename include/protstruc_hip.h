@@ -1,0 +1,150 @@
+/*
+ * protstruc_hip.h -- C ABI of libprotstruc_hip.so (gfx950 / MI355X).
+ *
+ * The reference (dohlee/protstruc v0.0.7) has no FFI: its geometry hot path is
+ * a set of Python methods on `StructureBatch` (protstruc/protstruc.py) and free
+ * functions in protstruc/geometry.py.  Each entry point below replaces the
+ * arithmetic of exactly one of those methods; the Python shell in
+ * `protstruc_amd/structure_batch.py` binds them with ctypes and keeps the
+ * reference's method signatures.  `file:line` citations are relative to the
+ * reference checkout.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never
+ *     allocates, frees or retains memory;
+ *   - coordinates are contiguous fp32 `xyz[B][N][A][3]`; masks are contiguous
+ *     one-byte booleans (0 / 1; any non-zero input byte counts as true);
+ *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream);
+ *   - launches are asynchronous, perform no allocation, no synchronisation and
+ *     no host read of device memory, so they may be captured into a hipGraph;
+ *   - the return value is a `hipError_t` as int (0 = success); argument errors
+ *     return hipErrorInvalidValue (1) before anything is launched.
+ */
+#ifndef PROTSTRUC_HIP_H
+#define PROTSTRUC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ABI version of this header (bumped on any signature change). */
+int ps_abi_version(void);
+
+/* Human-readable text for a code returned by any ps_* function. */
+const char* ps_error_string(int code);
+
+/*
+ * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
+ * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
+ * "k1_variant" (0 = default).
+ * Not part of the drop-in surface; has no reference counterpart.
+ */
+int ps_set_tuning(const char* key, int value);
+int ps_get_tuning(const char* key, int* value);
+
+/*
+ * K1 -- replaces StructureBatch.pairwise_distance_matrix (protstruc.py:455-484).
+ *
+ *   dist[b][i][j][a][c]      = | xyz[b][i][a] - xyz[b][j][c] |_2            (fp32)
+ *   dist_mask[b][i][j][a][c] = atom_mask[b][i][a] && atom_mask[b][j][c]     (u8)
+ *
+ * The mask is NOT applied to dist (NaN / padded atoms propagate), as in the
+ * reference.  Only residue rows i in [row_begin, row_end) are produced, which is
+ * how the residue axis is sharded across GPUs.  The output buffers hold
+ * `out_rows` residue rows per structure and row i is written at local row
+ * `i - out_row_origin`:
+ *     full-size buffers:   out_rows = N,                   out_row_origin = 0
+ *     compact shard:       out_rows = row_end - row_begin, out_row_origin = row_begin
+ * `atom_mask` may be NULL (all atoms present); `dist_mask` may be NULL (mask
+ * plane not produced); `dist` may be NULL (only the mask plane produced).
+ */
+int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask,
+                             float* dist, uint8_t* dist_mask,
+                             int B, int N, int A,
+                             int row_begin, int row_end,
+                             int out_rows, int out_row_origin,
+                             void* stream);
+
+/*
+ * K2 -- replaces StructureBatch.backbone_dihedrals together with
+ * get_n_terminal_mask / get_c_terminal_mask (protstruc.py:435-453, :486-541)
+ * and geometry.dihedral (geometry.py:74-124).
+ *
+ *   dihedrals[b][i] = (phi, psi, omega), zero at the batch edge and at chain
+ *   termini; dihedral_mask[b][i] = !(nterm, cterm, cterm) && residue_mask[b][i].
+ * chain_idx is fp32 (NaN marks padding; NaN != NaN makes a terminus).
+ * Atom slots 0,1,2 (N, CA, C) of each residue are read.  Any of the four
+ * outputs may be NULL.
+ */
+int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_idx,
+                              const uint8_t* residue_mask,
+                              float* dihedrals, uint8_t* dihedral_mask,
+                              uint8_t* nterm, uint8_t* cterm,
+                              int B, int N, int A, void* stream);
+
+/*
+ * K3 -- replaces StructureBatch.pairwise_dihedrals / pairwise_planar_angles and
+ * the (B, N*N, n, 3) gather of _pairwise_xyz (protstruc.py:589-660), with
+ * geometry.dihedral / geometry.angle (geometry.py:39-124) evaluated per pair.
+ *
+ *   n_points == 4: out[b][i][j] = dihedral(p0, p1, p2, p3)
+ *   n_points == 3: out[b][i][j] = angle(p0, p1, p2)   (acos, no clamp -> NaN as in the reference)
+ * where p_k = xyz[b][ src[k] ? j : i ][ atom[k] ].  Rows i in
+ * [row_begin, row_end) are produced into an (B, out_rows, N) buffer with the same
+ * row addressing as K1.
+ */
+int ps_pairwise_angles_f32(const float* xyz, float* out,
+                           int B, int N, int A,
+                           int n_points, const int* src, const int* atom,
+                           int row_begin, int row_end,
+                           int out_rows, int out_row_origin,
+                           void* stream);
+
+/*
+ * K4 -- replaces StructureBatch.backbone_orientations + backbone_translations
+ * (protstruc.py:543-587) and geometry.gram_schmidt (geometry.py:413-439).
+ *
+ *   rot[b][i] (3x3 row-major) has columns e1 = unit(a3-a2),
+ *   e2 = unit((a1-a2) - (e1.(a1-a2)) e1), e3 = e1 x e2;  trans[b][i] = xyz[b][i][t_atom].
+ * Either output may be NULL.
+ */
+int ps_frames_f32(const float* xyz, float* rot, float* trans,
+                  int B, int N, int A, int a1, int a2, int a3, int t_atom,
+                  void* stream);
+
+/*
+ * K5 -- replaces StructureBatch.diffuse_xyz (protstruc.py:864-878), in place:
+ *   xyz[b] <- sqrt(1 - beta[b]) * xyz[b] + sqrt(beta[b]) * eps,  eps ~ N(0,1) iid.
+ * `n_per_struct` = N*A*3.  If `noise` is non-NULL it supplies eps (parity with
+ * the reference's deterministic part); otherwise eps comes from Philox4x32-10 +
+ * Box-Muller keyed by rng_state[0] (seed) at counter offset rng_state[1], and
+ * rng_state[1] is advanced on the device after the draw so that a captured
+ * graph replays with fresh noise.  rng_state is a device array of two uint64.
+ */
+int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_struct,
+                   uint64_t* rng_state, const float* noise, void* stream);
+
+/*
+ * K6 -- replaces StructureBatch.standardize (protstruc.py:696-734), in place,
+ * with per-structure statistics (what the reference computes at B == 1; its
+ * B > 1 broadcast is a defect):
+ *   cnt = sum(mask); mu = sum(nan_to_num(xyz*mask))/cnt;
+ *   std = sqrt(sum((nan_to_num(xyz)-mu)^2 * mask)/cnt); xyz <- (xyz-mu)/std.
+ * mu and std are (B,3) outputs.
+ */
+int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std,
+                       int B, int N, int A, void* stream);
+
+/*
+ * Replaces StructureBatch.unstandardize (protstruc.py:736-744), in place:
+ *   xyz[b] <- xyz[b] * scale[b] + shift[b]   per coordinate axis; scale, shift are (B,3).
+ */
+int ps_affine_f32(float* xyz, const float* scale, const float* shift,
+                  int B, int n_atoms_per_struct, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROTSTRUC_HIP_H */

@@ -1,0 +1,101 @@
+// K3 -- inter-residue dihedrals and planar angles over all residue pairs.
+// Replaces StructureBatch.pairwise_dihedrals / pairwise_planar_angles and the
+// (B, N*N, n_i+n_j, 3) gather of _pairwise_xyz (reference protstruc.py:589-660);
+// geometry.dihedral / geometry.angle (geometry.py:39-124) are evaluated per pair
+// in registers, so the 1.6 GB gather of the reference is never materialised.
+//
+// Layout of the sweep: a workgroup owns 256 column residues j (one per lane) and
+// IR row residues i of one structure.  The (up to four) points taken from residue
+// j are loaded once into registers; the points taken from residue i have a
+// wave-uniform address, so the compiler fetches them with scalar loads and they
+// ride in SGPRs.  Which point comes from which side is a template parameter
+// (SRC bit k = 1: point k from j), so all j-only sub-expressions (e.g. d - c for
+// the (2,2) split) are loop-invariant and hoisted out of the i loop, and nothing
+// is selected at run time.  Each store instruction writes 64 consecutive floats
+// of one output row.  4 bytes are written per pair against ~100 flops and an
+// atan2f / acosf: the kernel is VALU-bound, not HBM-bound.
+#include "ps_common.hpp"
+
+namespace {
+
+struct AtomSel {
+    int atom[4];
+};
+
+template <int NP, int SRC>
+__global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restrict__ xyz, float* __restrict__ out,
+                                                          int N, int A, AtomSel sel, int row_begin, int row_end,
+                                                          int out_rows, int out_row_origin, int IR) {
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = row_begin + blockIdx.y * IR;
+    const int i1 = min(i0 + IR, row_end);
+    const bool live = j < N;
+    const int jc = live ? j : N - 1;
+
+    const float* sj = xyz + ((size_t)b * N + jc) * (size_t)A * 3;
+    f3 pj[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) pj[k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
+
+    for (int i = i0; i < i1; ++i) {
+        const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
+        f3 p[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[k] : load3(si + sel.atom[k] * 3);
+        float v;
+        if constexpr (NP == 4)
+            v = dihedral4(p[0], p[1], p[2], p[3]);
+        else
+            v = angle3(p[0], p[1], p[2]);
+        if (live) out[((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j] = v;
+    }
+}
+
+template <int NP, int SRC>
+int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
+           int out_rows, int out_row_origin, hipStream_t s) {
+    const int IR = 16;
+    const int rows = row_end - row_begin;
+    dim3 grid((N + 255) / 256, (rows + IR - 1) / IR, B);
+    hipLaunchKernelGGL((k3_pairwise_angles<NP, SRC>), grid, dim3(256), 0, s, xyz, out, N, A, sel, row_begin, row_end,
+                       out_rows, out_row_origin, IR);
+    return ps_check_launch();
+}
+
+template <int NP, int... SRCS>
+int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin,
+             int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+    int rc = (int)hipErrorInvalidValue;
+    (void)((srcmask == SRCS
+                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s), true)
+                : false) ||
+           ...);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N, int A, int n_points, const int* src,
+                                      const int* atom, int row_begin, int row_end, int out_rows, int out_row_origin,
+                                      void* stream) {
+    if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0 || B > 65535) return (int)hipErrorInvalidValue;
+    if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
+    if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
+    if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
+    AtomSel sel{};
+    int srcmask = 0;
+    for (int k = 0; k < n_points; ++k) {
+        if (atom[k] < 0 || atom[k] >= A || (src[k] != 0 && src[k] != 1)) return (int)hipErrorInvalidValue;
+        sel.atom[k] = atom[k];
+        srcmask |= src[k] << k;
+    }
+    if (B == 0 || N == 0 || row_begin == row_end) return 0;
+    if ((row_end - row_begin + 15) / 16 > 65535) return (int)hipErrorInvalidValue;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n_points == 4)
+        return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(
+            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+    return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
+                                               out_row_origin, s);
+}

@@ -1,0 +1,561 @@
+// K1 -- all-atom pairwise distance matrix + pair mask.
+// Replaces StructureBatch.pairwise_distance_matrix (reference protstruc.py:455-484).
+//
+// The output of one (structure b, residue row i) is one contiguous run of
+// N*A*A floats (and N*A*A mask bytes): dist[b][i][0..N)[0..A)[0..A).  The kernel
+// is a pure HBM *write* stream -- 1125 bytes written per residue pair at A = 15
+// against ~1 byte read -- so everything is organised around emitting that
+// stream as 16-byte-per-lane stores in address order:
+//
+//   * a workgroup owns a tile of JT column residues j and IR row residues i of
+//     one structure; the 15 atoms of each staged residue sit in LDS padded to
+//     float4 (one ds_read_b128 per atom) and the 15 atom-mask bytes of a
+//     residue are packed into 15 bits;
+//   * the (i, j-tile) run is cut into float4 slots in address order; a lane
+//     decodes the slot's first element into (j, a, c) with constant divisions
+//     (225 = 15*15, 15) and walks the next three elements with carry logic;
+//   * the mask run is cut into 16-byte slots; a slot is a 16-bit window of the
+//     concatenated 15-bit rows (m_i[a] ? bits(m_j) : 0), expanded bit->byte
+//     with one multiply per four bytes;
+//   * rows that are not 16-byte aligned (N % 4 != 0 for dist, N % 16 != 0 for
+//     the mask) shift the slot grid so stores stay aligned and the ragged head
+//     and tail are written element-wise.
+//
+// Any A other than 15 takes the generic element-per-lane kernel at the bottom.
+#include "ps_common.hpp"
+#include <string.h>
+
+namespace {
+
+constexpr int A15 = 15;
+constexpr int AA15 = 225;
+
+struct K1Tuning {
+    // Measured on MI355X at B=64, N=512 (tools/k1_probe.py): plain stores beat non-temporal ones for the
+    // pattern kernel (its 3600-byte groups are not 128-byte aligned, so lines are completed by a second
+    // wave and want to merge in L2), and one row per workgroup (small granules written in address order)
+    // beats 4..16 rows.
+    int store_nt = 0;
+    int rows_per_block = 1;   // IR
+    int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
+    int jt = 64;              // column residues per tile (64 or 128)
+};
+K1Tuning g_k1;
+
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+    u32x4_t w = {v.x, v.y, v.z, v.w};
+    if (NT)
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
+    else
+        *reinterpret_cast<u32x4_t*>(p) = w;
+}
+
+// Correctly rounded sqrt for x >= 0 without the subnormal pre-scaling of the
+// library routine: v_sqrt_f32 is within 1 ulp, so the answer is s-1ulp, s or
+// s+1ulp and two exact fma residuals pick it.  0, inf and NaN fall through
+// unchanged (every comparison with a NaN residual is false).  A squared
+// distance below 1.2e-38 (atoms closer than 1e-19) would lose correct rounding,
+// nothing else.
+__device__ __forceinline__ float sqrt_rn_pos(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u);
+    const float hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_lo = __builtin_fmaf(-lo, s, x);
+    const float r_hi = __builtin_fmaf(-hi, s, x);
+    float r = s;
+    r = (r_lo <= 0.0f) ? lo : r;
+    r = (r_hi > 0.0f) ? hi : r;
+    return r;
+}
+
+__device__ __forceinline__ float dist_pp(float4 p, float4 q) {
+    float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    return sqrt_rn_pos((sx + sy) + sz);
+}
+
+// four bits -> four bytes of 0/1 (bit k lands in byte k)
+__device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x00204081u) & 0x01010101u; }
+
+// JT: column residues per tile (multiple of 16 so both planes split into whole 16-byte slots)
+// DA / MA: every (i, j-tile) run of the distance / mask plane starts on a 16-byte
+// boundary and is a whole number of 16-byte slots (N % 4 == 0 resp. N % 16 == 0
+// and an aligned base pointer) -- the branch-free path.
+template <int JT, bool NT, bool DA, bool MA>
+__global__ __launch_bounds__(256) void k1_pairdist_a15(const float* __restrict__ xyz,
+                                                       const uint8_t* __restrict__ amask,
+                                                       float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                       int N, int row_begin, int row_end, int out_rows,
+                                                       int out_row_origin, int IR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS carve: xj[JT*15] float4 | xi[IR*15] float4 | mj[JT+1] u32 | mi[IR] u32
+    float4* sxj = reinterpret_cast<float4*>(smem);
+    float4* sxi = sxj + JT * A15;
+    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A15);
+    uint32_t* smi = smj + (JT + 4);
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int j0 = blockIdx.x * JT;
+    const int jn = min(JT, N - j0);
+    const int i0 = row_begin + blockIdx.y * IR;
+    const int in = min(IR, row_end - i0);
+
+    // ---- stage the coordinate tiles (coalesced dword loads of the flat rows) ----
+    {
+        const float* gj = xyz + ((size_t)b * N + j0) * (A15 * 3);
+        float* lj = reinterpret_cast<float*>(sxj);
+        for (int f = tid; f < jn * (A15 * 3); f += 256) {
+            int atom = f / 3, comp = f - atom * 3;
+            lj[atom * 4 + comp] = gj[f];
+        }
+        const float* gi = xyz + ((size_t)b * N + i0) * (A15 * 3);
+        float* li = reinterpret_cast<float*>(sxi);
+        for (int f = tid; f < in * (A15 * 3); f += 256) {
+            int atom = f / 3, comp = f - atom * 3;
+            li[atom * 4 + comp] = gi[f];
+        }
+        // 15 mask bytes of a residue -> 15 bits
+        for (int r = tid; r < JT + 4 + IR; r += 256) {
+            bool is_j = r < JT + 4;
+            int rl = is_j ? r : r - (JT + 4);
+            bool valid = is_j ? (rl < jn) : (rl < in);
+            uint32_t bits = 0;
+            if (valid) {
+                if (amask) {
+                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A15;
+#pragma unroll
+                    for (int c = 0; c < A15; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+                } else {
+                    bits = 0x7FFFu;
+                }
+            }
+            (is_j ? smj : smi)[rl] = bits;
+        }
+    }
+    __syncthreads();
+
+    const unsigned nE = (unsigned)jn * AA15;  // elements of one (i, j-tile) run
+
+    // =========================== distance plane ===========================
+    if (dist) {
+        for (int il = 0; il < in; ++il) {
+            const size_t obase = (((size_t)b * out_rows + (size_t)(i0 + il - out_row_origin)) * N + j0) * AA15;
+            float* orow = dist + obase;
+            // misalignment of the run in floats; slot q covers elements [4q - sh, 4q - sh + 4)
+            const unsigned sh = (unsigned)((reinterpret_cast<uintptr_t>(orow) >> 2) & 3u);
+            const unsigned nQ = (nE + sh + 3u) >> 2;
+            const unsigned ibase = (unsigned)il * A15;
+            if (DA) {
+                for (unsigned q = tid; q < (nE >> 2); q += 256) {
+                    const unsigned e0 = 4u * q;
+                    const unsigned jl = e0 / AA15;
+                    const unsigned r = e0 - jl * AA15;
+                    unsigned a = r / A15;
+                    unsigned c = r - a * A15;
+                    unsigned ja = jl * A15 + c;
+                    unsigned ia = ibase + a;
+                    float v[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        v[t] = dist_pp(sxi[ia], sxj[ja]);
+                        // advance (a, c) -> next element; carries are selects, not branches
+                        const bool wc = (c == A15 - 1);
+                        const bool wa = wc && (a == A15 - 1);
+                        c = wc ? 0u : c + 1u;
+                        a = wa ? 0u : (wc ? a + 1u : a);
+                        ja = wa ? ja + 1u : (wc ? ja - (A15 - 1) : ja + 1u);
+                        ia = wa ? ia - (A15 - 1) : (wc ? ia + 1u : ia);
+                    }
+                    uint4 u = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                         __float_as_uint(v[3]));
+                    store16<NT>(orow + e0, u);
+                }
+                continue;
+            }
+            for (unsigned q = tid; q < nQ; q += 256) {
+                const int e0 = (int)(4u * q) - (int)sh;
+                const unsigned ef = e0 < 0 ? 0u : (unsigned)e0;  // first in-range element of the slot
+                unsigned jl = ef / AA15;
+                unsigned r = ef - jl * AA15;
+                unsigned a = r / A15;
+                unsigned c = r - a * A15;
+                unsigned ja = jl * A15 + c;
+                unsigned ia = ibase + a;
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = e0 + t;
+                    if (e >= 0 && (unsigned)e < nE) {
+                        v[t] = dist_pp(sxi[ia], sxj[ja]);
+                        ++c;
+                        ++ja;
+                        if (c == A15) {
+                            c = 0;
+                            ja -= A15;
+                            ++a;
+                            ++ia;
+                            if (a == A15) {
+                                a = 0;
+                                ia -= A15;
+                                ja += A15;
+                            }
+                        }
+                    } else {
+                        v[t] = 0.f;
+                    }
+                }
+                if (e0 >= 0 && (unsigned)(e0 + 4) <= nE) {
+                    uint4 u = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                         __float_as_uint(v[3]));
+                    store16<NT>(orow + e0, u);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = e0 + t;
+                        if (e >= 0 && (unsigned)e < nE) orow[e] = v[t];
+                    }
+                }
+            }
+        }
+    }
+
+    // ============================= mask plane =============================
+    if (dmask) {
+        for (int il = 0; il < in; ++il) {
+            const size_t obase = (((size_t)b * out_rows + (size_t)(i0 + il - out_row_origin)) * N + j0) * AA15;
+            uint8_t* orow = dmask + obase;
+            const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(orow) & 15u);
+            const unsigned nQ = (nE + sh + 15u) >> 4;
+            const uint32_t mib = smi[il];
+            if (MA) {
+                for (unsigned q = tid; q < (nE >> 4); q += 256) {
+                    const unsigned e0 = 16u * q;
+                    const unsigned jl = e0 / AA15;
+                    const unsigned r = e0 - jl * AA15;
+                    const unsigned a = r / A15;
+                    const unsigned c = r - a * A15;
+                    const bool wa = (a == A15 - 1);
+                    const unsigned a1 = wa ? 0u : a + 1u;
+                    const unsigned jl1 = wa ? jl + 1u : jl;
+                    const uint32_t row0 = ((mib >> a) & 1u) ? smj[jl] : 0u;
+                    const uint32_t row1 = ((mib >> a1) & 1u) ? smj[jl1] : 0u;
+                    const uint32_t win = (row0 | (row1 << 15)) >> c;
+                    uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                         spread4((win >> 12) & 15u));
+                    store16<NT>(orow + e0, u);
+                }
+                continue;
+            }
+            for (unsigned q = tid; q < nQ; q += 256) {
+                const int e0 = (int)(16u * q) - (int)sh;
+                const unsigned ef = e0 < 0 ? 0u : (unsigned)e0;
+                const unsigned lead = (unsigned)((int)ef - e0);  // slot bytes before the run starts
+                unsigned jl = ef / AA15;
+                unsigned r = ef - jl * AA15;
+                unsigned a = r / A15;
+                unsigned c = r - a * A15;
+                // 16-bit window starting at bit c of row (jl,a) | row(next) << 15 [| row(next2) << 30]
+                unsigned a1 = a + 1, jl1 = jl;
+                if (a1 == A15) {
+                    a1 = 0;
+                    ++jl1;
+                }
+                uint32_t row0 = ((mib >> a) & 1u) ? smj[jl] : 0u;
+                uint32_t row1 = ((mib >> a1) & 1u) ? smj[jl1] : 0u;
+                uint32_t win = ((row0 | (row1 << 15)) >> c) & 0xFFFFu;  // c + 16 <= 30
+                // bits past the end of this run belong to nobody (rows >= jn hold 0 bits)
+                if (e0 >= 0 && (unsigned)(e0 + 16) <= nE) {
+                    uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                         spread4((win >> 12) & 15u));
+                    store16<NT>(orow + e0, u);
+                } else {
+                    for (unsigned t = lead; t < 16u; ++t) {
+                        const unsigned e = (unsigned)(e0 + (int)t);
+                        if (e < nE) orow[e] = (uint8_t)((win >> (t - lead)) & 1u);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- pattern kernel (aligned shapes: N % 16 == 0, 16-byte aligned planes) ----
+// 4 column residues are 900 floats = exactly 225 float4 slots, and 16 column
+// residues are 3600 mask bytes = exactly 225 16-byte slots.  So if lane t
+// (t < 225) always takes slot t of a group, its four elements keep the SAME
+// (j offset, a, c) in every group and every row: the index decode happens once
+// per workgroup, the row atoms xi[a] it needs live in registers for a whole row,
+// and the inner loop is LDS read (immediate offsets) -> 4 distances -> one
+// 16-byte store, with no integer arithmetic besides the address bump.  31 of 256
+// lanes idle in the sweep (they still help with staging).
+//
+// LDS image: a residue is 16 float4 slots (15 atoms + 1 pad) = 256 bytes = one
+// full row of the 64 LDS banks, and atoms are fetched with ds_read_b128 (the
+// loads are volatile so the compiler cannot narrow them to the 8-cycle b96
+// form).  Lanes of one 16-lane service group that read the same residue then
+// touch distinct banks (different atoms) or broadcast (same atom): conflict-free
+// except where a group straddles two residues.
+constexpr int RS = 16;  // float4 slots per staged residue
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+typedef const volatile f32x4_t __attribute__((address_space(3))) * lds_f32x4_ptr;
+
+__device__ __forceinline__ float4 lds_atom(const float4* p) {
+    const f32x4_t v = *(lds_f32x4_ptr)(p);  // generic -> LDS address space, volatile: stays one ds_read_b128
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
+template <int JT, bool NT>
+__global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restrict__ xyz,
+                                                           const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                           int N, int row_begin, int row_end, int out_rows,
+                                                           int out_row_origin, int IR) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float4* sxj = reinterpret_cast<float4*>(smem);
+    float4* sxi = sxj + JT * RS;
+    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * RS);
+    uint32_t* smi = smj + (JT + 4);
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int j0 = blockIdx.x * JT;
+    const int jn = min(JT, N - j0);  // multiple of 16
+    const int i0 = row_begin + blockIdx.y * IR;
+    const int in = min(IR, row_end - i0);
+
+    {
+        const float* gj = xyz + ((size_t)b * N + j0) * (A15 * 3);
+        float* lj = reinterpret_cast<float*>(sxj);
+        for (int f = tid; f < jn * (A15 * 3); f += 256) {
+            int atom = f / 3, comp = f - atom * 3;
+            int res = atom / A15, c = atom - res * A15;
+            lj[(res * RS + c) * 4 + comp] = gj[f];
+        }
+        const float* gi = xyz + ((size_t)b * N + i0) * (A15 * 3);
+        float* li = reinterpret_cast<float*>(sxi);
+        for (int f = tid; f < in * (A15 * 3); f += 256) {
+            int atom = f / 3, comp = f - atom * 3;
+            int res = atom / A15, c = atom - res * A15;
+            li[(res * RS + c) * 4 + comp] = gi[f];
+        }
+        for (int r = tid; r < JT + 4 + IR; r += 256) {
+            bool is_j = r < JT + 4;
+            int rl = is_j ? r : r - (JT + 4);
+            bool valid = is_j ? (rl < jn) : (rl < in);
+            uint32_t bits = 0;
+            if (valid) {
+                if (amask) {
+                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A15;
+#pragma unroll
+                    for (int c = 0; c < A15; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+                } else {
+                    bits = 0x7FFFu;
+                }
+            }
+            (is_j ? smj : smi)[rl] = bits;
+        }
+    }
+    __syncthreads();
+    if (tid >= AA15) return;  // no barrier below
+
+    const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;  // pair index of (i0, j0)
+
+    if (dist) {
+        unsigned offj[4], ai[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned e = 4u * tid + k;  // element inside a 4-residue group
+            const unsigned jo = e / AA15, r = e - jo * AA15;
+            const unsigned a = r / A15, c = r - a * A15;
+            offj[k] = jo * RS + c;
+            ai[k] = a;
+        }
+        const int ngroups = jn >> 2;
+        for (int il = 0; il < in; ++il) {
+            float4 pi[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) pi[k] = sxi[il * RS + ai[k]];
+            float* o = dist + (row0 + (size_t)il * N) * AA15 + 4u * tid;
+            const float4* xj = sxj;
+#pragma unroll 4
+            for (int g = 0; g < ngroups; ++g) {
+                const float4 q0 = lds_atom(xj + offj[0]), q1 = lds_atom(xj + offj[1]);
+                const float4 q2 = lds_atom(xj + offj[2]), q3 = lds_atom(xj + offj[3]);
+                uint4 u;
+                u.x = __float_as_uint(dist_pp(pi[0], q0));
+                u.y = __float_as_uint(dist_pp(pi[1], q1));
+                u.z = __float_as_uint(dist_pp(pi[2], q2));
+                u.w = __float_as_uint(dist_pp(pi[3], q3));
+                store16<NT>(o, u);
+                o += 4 * AA15;
+                xj += 4 * RS;
+            }
+        }
+    }
+
+    if (dmask) {
+        const unsigned e0 = 16u * tid;  // byte inside a 16-residue group
+        const unsigned jo = e0 / AA15, r = e0 - jo * AA15;
+        const unsigned a = r / A15, c = r - a * A15;
+        const bool wa = (a == A15 - 1);
+        const unsigned a1 = wa ? 0u : a + 1u;
+        const unsigned jo1 = wa ? jo + 1u : jo;
+        constexpr int NG = JT / 16;
+        uint32_t mj0[NG], mj1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            mj0[g] = smj[g * 16 + jo];
+            mj1[g] = smj[g * 16 + jo1] << 15;
+        }
+        const int ngroups = jn >> 4;
+        for (int il = 0; il < in; ++il) {
+            const uint32_t mib = smi[il];
+            const uint32_t k0 = ((mib >> a) & 1u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t k1 = ((mib >> a1) & 1u) ? 0xFFFFFFFFu : 0u;
+            uint8_t* o = dmask + (row0 + (size_t)il * N) * AA15 + 16u * tid;
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < ngroups) {
+                    const uint32_t win = ((mj0[g] & k0) | (mj1[g] & k1)) >> c;
+                    uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                         spread4((win >> 12) & 15u));
+                    store16<NT>(o + (size_t)g * (16 * AA15), u);
+                }
+            }
+        }
+    }
+}
+
+// ---- generic A: one output element per lane, runtime decode, scalar stores ----
+__global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
+                                                           const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                           int N, int A, int row_begin, int row_end, int out_rows,
+                                                           int out_row_origin) {
+    const int b = blockIdx.z;
+    const int i = row_begin + blockIdx.y;
+    const unsigned AA = (unsigned)A * A;
+    const unsigned nE = (unsigned)N * AA;
+    const size_t obase = (((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N) * AA;
+    const float* xi = xyz + ((size_t)b * N + i) * A * 3;
+    const uint8_t* mi = amask ? amask + ((size_t)b * N + i) * A : nullptr;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < nE; e += gridDim.x * 256u) {
+        unsigned j = e / AA;
+        unsigned r = e - j * AA;
+        unsigned a = r / (unsigned)A;
+        unsigned c = r - a * (unsigned)A;
+        const float* xj = xyz + (((size_t)b * N + j) * A + c) * 3;
+        const float* xa = xi + a * 3;
+        if (dist) {
+            float dx = xa[0] - xj[0], dy = xa[1] - xj[1], dz = xa[2] - xj[2];
+            float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+            dist[obase + e] = sqrtf((sx + sy) + sz);
+        }
+        if (dmask) {
+            uint8_t v = 1;
+            if (mi) v = (mi[a] != 0) && (amask[((size_t)b * N + j) * A + c] != 0);
+            dmask[obase + e] = v;
+        }
+    }
+}
+
+template <int JT>
+int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int row_begin,
+               int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+    const int IR = g_k1.rows_per_block;
+    const int rows = row_end - row_begin;
+    dim3 grid((N + JT - 1) / JT, (rows + IR - 1) / IR, B);
+    size_t lds = (size_t)(JT + IR) * A15 * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
+    const bool da = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
+    const bool ma = (N % 16 == 0) && ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0);
+#define PS_K1_LAUNCH(NT_, DA_, MA_)                                                                                  \
+    hipLaunchKernelGGL((k1_pairdist_a15<JT, NT_, DA_, MA_>), grid, dim3(256), lds, s, xyz, amask, dist, dmask, N,    \
+                       row_begin, row_end, out_rows, out_row_origin, IR)
+    if (da && ma && g_k1.variant == 0) {
+        const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
+        if (g_k1.store_nt)
+            hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, true>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N,
+                               row_begin, row_end, out_rows, out_row_origin, IR);
+        else
+            hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, false>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N,
+                               row_begin, row_end, out_rows, out_row_origin, IR);
+    } else if (da && ma) {
+        if (g_k1.store_nt) PS_K1_LAUNCH(true, true, true);
+        else PS_K1_LAUNCH(false, true, true);
+    } else if (da) {
+        PS_K1_LAUNCH(true, true, false);
+    } else {
+        PS_K1_LAUNCH(true, false, false);
+    }
+#undef PS_K1_LAUNCH
+    return ps_check_launch();
+}
+
+}  // namespace
+
+extern "C" int ps_k1_set_tuning(const char* key, int value);
+extern "C" int ps_k1_get_tuning(const char* key, int* value);
+
+int ps_k1_set_tuning(const char* key, int value) {
+    if (!strcmp(key, "k1_store_nt")) {
+        g_k1.store_nt = value ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "k1_rows_per_block")) {
+        if (value < 1 || value > 32) return (int)hipErrorInvalidValue;
+        g_k1.rows_per_block = value;
+        return 0;
+    }
+    if (!strcmp(key, "k1_variant")) {
+        g_k1.variant = value;
+        return 0;
+    }
+    if (!strcmp(key, "k1_jt")) {
+        if (value != 64 && value != 128) return (int)hipErrorInvalidValue;
+        g_k1.jt = value;
+        return 0;
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+int ps_k1_get_tuning(const char* key, int* value) {
+    if (!strcmp(key, "k1_store_nt")) *value = g_k1.store_nt;
+    else if (!strcmp(key, "k1_rows_per_block")) *value = g_k1.rows_per_block;
+    else if (!strcmp(key, "k1_variant")) *value = g_k1.variant;
+    else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
+    else return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask,
+                                        int B, int N, int A, int row_begin, int row_end, int out_rows,
+                                        int out_row_origin, void* stream) {
+    if (!xyz || (!dist && !dist_mask) || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
+    if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
+    if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
+    if (B > 65535) return (int)hipErrorInvalidValue;
+    if (B == 0 || N == 0 || row_begin == row_end) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rows = row_end - row_begin;
+    if (A == A15) {
+        if ((rows + g_k1.rows_per_block - 1) / g_k1.rows_per_block > 65535) return (int)hipErrorInvalidValue;
+        if (g_k1.jt == 128)
+            return launch_a15<128>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
+                                   s);
+        return launch_a15<64>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+    }
+    if (rows > 65535) return (int)hipErrorInvalidValue;
+    const unsigned long long nE = (unsigned long long)N * A * A;
+    if (nE > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
+    unsigned gx = (unsigned)((nE + 255) / 256);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(k1_pairdist_generic, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist, dist_mask, N, A,
+                       row_begin, row_end, out_rows, out_row_origin);
+    return ps_check_launch();
+}

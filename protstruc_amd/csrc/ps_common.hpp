@@ -1,0 +1,78 @@
+// Shared device helpers for the protstruc geometry kernels (gfx950 only).
+//
+// Every translation unit is compiled with -ffp-contract=off: the reference's
+// arithmetic is a chain of separate ATen / numpy multiplies, adds and
+// subtracts, and fused multiply-adds change results that must be *exact*
+// zeros there (e.g. the diagonal of pairwise_dihedrals, SURVEY hard part 4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define PS_WAVE 64
+
+struct f3 {
+    float x, y, z;
+};
+
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 scale3(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 div3(f3 a, float s) { return f3{a.x / s, a.y / s, a.z / s}; }
+
+// (x*y).sum(-1): products first, then adds (geometry.py:24-26).  ATen's sum
+// accumulates from +0, so a dot product whose three terms are all -0 is +0 in
+// the reference; that sign decides atan2(0, x) on degenerate (i == j) pairs, so
+// the leading `0 +` is part of the contract (it is exact for every other input).
+__device__ __forceinline__ float dot3(f3 a, f3 b) {
+    float px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
+    return ((0.0f + px) + py) + pz;
+}
+
+// x.norm(dim=-1) (geometry.py:29-31); sqrtf is the correctly rounded one
+__device__ __forceinline__ float norm3(f3 a) { return sqrtf(dot3(a, a)); }
+
+// np.cross component order: u1*v2 - u2*v1, ... two products then one subtract
+__device__ __forceinline__ f3 cross3(f3 u, f3 v) {
+    f3 r;
+    r.x = u.y * v.z - u.z * v.y;
+    r.y = u.z * v.x - u.x * v.z;
+    r.z = u.x * v.y - u.y * v.x;
+    return r;
+}
+
+// geometry.dihedral (geometry.py:108-124)
+__device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
+    f3 b0 = sub3(a, b);
+    f3 b1 = sub3(c, b);
+    f3 b2 = sub3(d, c);
+    f3 n1 = cross3(b0, b1);
+    f3 n2 = cross3(b2, b1);
+    f3 m = cross3(n1, n2);
+    float x = dot3(n1, n2);
+    float y = dot3(m, b1) / norm3(b1);
+    return atan2f(y, x);
+}
+
+// geometry.angle (geometry.py:64-71): no clamp before acos
+__device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
+    f3 ba = sub3(a, b);
+    f3 bc = sub3(c, b);
+    float cosine = dot3(ba, bc) / (norm3(ba) * norm3(bc));
+    return acosf(cosine);
+}
+
+// geometry.gram_schmidt (geometry.py:428-439); e3 uses the last-axis cross
+__device__ __forceinline__ void gram_schmidt3(f3 a, f3 b, f3 c, f3& e1, f3& e2, f3& e3) {
+    f3 v1 = sub3(c, b);
+    e1 = div3(v1, norm3(v1));
+    f3 v2 = sub3(a, b);
+    float p = dot3(e1, v2);
+    f3 u2 = sub3(v2, scale3(e1, p));
+    e2 = div3(u2, norm3(u2));
+    e3 = cross3(e1, e2);
+}
+
+__device__ __forceinline__ f3 load3(const float* __restrict__ p) { return f3{p[0], p[1], p[2]}; }
+
+static inline int ps_check_launch() { return (int)hipGetLastError(); }

@@ -1,0 +1,194 @@
+"""Tensor-level wrappers over the C ABI (include/protstruc_hip.h).
+
+Each function takes device tensors, allocates the outputs with PyTorch (the
+caller owns every buffer; the library never allocates) and launches on
+PyTorch's current HIP stream, so calls order with surrounding torch ops and can
+be captured by ``torch.cuda.graph``.  Inputs on the CPU raise: there is no
+CPU path in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"protstruc_amd: `{name}` lives on {t.device}; the geometry kernels are HIP-only "
+            "(no CPU fallback). Move the batch to the GPU first (StructureBatch(..., device='cuda')).")
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    _require_device(t, name)
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t.contiguous()
+
+
+def _u8c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
+    """Truth value of a mask as contiguous uint8 0/1 (bool tensors are reinterpreted, not copied)."""
+    if t is None:
+        return None
+    _require_device(t, name)
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    return (t != 0).contiguous().view(torch.uint8)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(t: torch.Tensor):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
+                      row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
+                      out_dist: Optional[torch.Tensor] = None, out_mask: Optional[torch.Tensor] = None,
+                      want_dist: bool = True, want_mask: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """K1.  Returns (dist fp32, dist_mask bool) of shape (B, rows, N, A, A).
+
+    rows = N for the default full matrix.  With ``row_begin/row_end`` only those
+    residue rows are computed: into a compact (B, row_end-row_begin, N, A, A)
+    buffer if ``compact`` else into rows [row_begin,row_end) of a full-size
+    buffer (``out_dist`` / ``out_mask`` may supply that buffer, e.g. the
+    destination of an all-gather)."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    row_end = N if row_end is None else row_end
+    if not (0 <= row_begin <= row_end <= N):
+        raise ValueError(f"row range [{row_begin},{row_end}) outside [0,{N})")
+    out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
+    shape = (B, out_rows, N, A, A)
+    mask_u8 = _u8c(atom_mask, "atom_mask")
+    with torch.cuda.device(xyz.device):
+        dist = dmask = None
+        if want_dist:
+            dist = out_dist if out_dist is not None else torch.empty(shape, dtype=torch.float32, device=xyz.device)
+            if dist.shape != shape or dist.dtype != torch.float32 or not dist.is_contiguous():
+                raise ValueError(f"out_dist must be a contiguous float32 tensor of shape {shape}")
+        if want_mask:
+            dmask = out_mask if out_mask is not None else torch.empty(shape, dtype=torch.bool, device=xyz.device)
+            if dmask.shape != shape or dmask.dtype != torch.bool or not dmask.is_contiguous():
+                raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
+        rc = _lib.load().ps_pairwise_distance_f32(
+            _ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin,
+            _stream(xyz))
+    _lib.check(rc, "ps_pairwise_distance_f32")
+    return dist, dmask
+
+
+def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask: torch.Tensor):
+    """K2.  Returns (dihedrals (B,N,3) fp32, dihedral_mask (B,N,3) bool, nterm (B,N) bool, cterm (B,N) bool)."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    chain = _f32c(chain_idx, "chain_idx")
+    rmask = _u8c(residue_mask, "residue_mask")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        dih = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        dmask = torch.empty(B, N, 3, dtype=torch.bool, device=dev)
+        nterm = torch.empty(B, N, dtype=torch.bool, device=dev)
+        cterm = torch.empty(B, N, dtype=torch.bool, device=dev)
+        rc = _lib.load().ps_backbone_dihedrals_f32(
+            _ptr(xyz), _ptr(chain), _ptr(rmask), _ptr(dih), _ptr(dmask), _ptr(nterm), _ptr(cterm), B, N, A,
+            _stream(xyz))
+    _lib.check(rc, "ps_backbone_dihedrals_f32")
+    return dih, dmask, nterm, cterm
+
+
+def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence[int], n_points: int, *,
+                    row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False) -> torch.Tensor:
+    """K3.  n_points = 4: dihedral, 3: planar angle, over points (slots_i of residue i ++ slots_j of residue j)."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    slots = [int(s) for s in slots_i] + [int(s) for s in slots_j]
+    src = [0] * len(slots_i) + [1] * len(slots_j)
+    if len(slots) < n_points:
+        raise IndexError(f"need {n_points} atoms in total, got {len(slots)}")  # the reference indexes past the end
+    slots, src = slots[:n_points], src[:n_points]
+    row_end = N if row_end is None else row_end
+    out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
+    arr = ctypes.c_int * n_points
+    with torch.cuda.device(xyz.device):
+        out = torch.empty(B, out_rows, N, dtype=torch.float32, device=xyz.device)
+        rc = _lib.load().ps_pairwise_angles_f32(
+            _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
+            _stream(xyz))
+    _lib.check(rc, "ps_pairwise_angles_f32")
+    return out
+
+
+def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, want_rot: bool = True,
+           want_trans: bool = True):
+    """K4.  Returns (rot (B,N,3,3) or None, trans (B,N,3) or None)."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        rot = torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None
+        trans = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_trans else None
+        rc = _lib.load().ps_frames_f32(_ptr(xyz), _ptr(rot), _ptr(trans), B, N, A, int(a1), int(a2), int(a3),
+                                       int(t_atom), _stream(xyz))
+    _lib.check(rc, "ps_frames_f32")
+    return rot, trans
+
+
+def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Tensor] = None,
+             noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K5, in place on a contiguous fp32 ``xyz``.  ``rng_state``: int64 device tensor [seed, offset]."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("diffuse_ needs a contiguous float32 xyz (it is updated in place)")
+    B = xyz.shape[0]
+    nps = xyz[0].numel() if B else 0
+    beta = _f32c(beta, "beta")
+    if beta.shape != (B,):
+        raise ValueError(f"beta must have shape ({B},), got {tuple(beta.shape)}")
+    if noise is not None:
+        noise = _f32c(noise, "noise")
+        if noise.shape != xyz.shape:
+            raise ValueError("noise must have the shape of xyz")
+    elif rng_state is None:
+        raise ValueError("either rng_state or noise is required")
+    with torch.cuda.device(xyz.device):
+        rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
+    _lib.check(rc, "ps_diffuse_f32")
+    return xyz
+
+
+def standardize_(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor]):
+    """K6, in place.  Returns (mu (B,3), std (B,3))."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("standardize_ needs a contiguous float32 xyz (it is updated in place)")
+    B, N, A = xyz.shape[:3]
+    m = _u8c(atom_mask, "atom_mask")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        mu = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        std = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        rc = _lib.load().ps_standardize_f32(_ptr(xyz), _ptr(m), _ptr(mu), _ptr(std), B, N, A, _stream(xyz))
+    _lib.check(rc, "ps_standardize_f32")
+    return mu, std
+
+
+def affine_(xyz: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """xyz[b] <- xyz[b] * scale[b] + shift[b] per axis, in place (unstandardize)."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("affine_ needs a contiguous float32 xyz (it is updated in place)")
+    B = xyz.shape[0]
+    n_atoms = xyz[0].numel() // 3 if B else 0
+    scale = _f32c(scale, "scale")
+    shift = _f32c(shift, "shift")
+    with torch.cuda.device(xyz.device):
+        rc = _lib.load().ps_affine_f32(_ptr(xyz), _ptr(scale), _ptr(shift), B, n_atoms, _stream(xyz))
+    _lib.check(rc, "ps_affine_f32")
+    return xyz

@@ -1,0 +1,259 @@
+"""`StructureBatch` -- the reference's batch API, with the geometry on MI355X.
+
+Drop-in for the geometric-feature hot path of ``protstruc.StructureBatch``
+(reference protstruc/protstruc.py:32-956): same constructor, method names,
+argument meaning, return arity / shape / dtype and exception types; the
+arithmetic of every featuriser runs in the hand-written HIP kernels of
+``libprotstruc_hip.so`` (see include/protstruc_hip.h).  There is no CPU path:
+a batch that lives on the CPU can be constructed and inspected, but calling a
+featuriser on it raises.
+
+Deliberate, documented differences from the reference (SURVEY.md quirk list):
+
+* device: every derived tensor lives on ``xyz``'s device (the reference
+  hard-codes CPU, protstruc.py:71-73,84); CPU / numpy inputs are moved to the
+  current GPU when one is present (``device=`` overrides).
+* Q1 ``standardize`` uses per-structure statistics for any batch size (the
+  reference only runs for B == 1).  Q3/Q4: its mask arguments work.
+* Q2 ``pairwise_distance_matrix`` without an ``atom_mask`` returns an all-True
+  mask instead of raising ``TypeError``.
+* Q6 the third frame axis is the last-axis cross product for every shape.
+* Q8 ``diffuse_xyz`` / ``standardize`` / ``unstandardize`` update the coordinate
+  buffer in place (hipGraph-friendly); earlier ``get_xyz()`` results alias it.
+* coordinates are held as contiguous float32 (float64 input is down-cast).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import ops
+from .general import ATOM
+
+
+def _always_tensor(x):
+    return torch.from_numpy(x) if isinstance(x, np.ndarray) else x
+
+
+def _default_device() -> torch.device:
+    if torch.cuda.is_available():
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+class StructureBatch:
+    """A padded batch of protein structures: ``xyz (B, N_res, N_atom, 3)`` + masks."""
+
+    def __init__(
+        self,
+        xyz: torch.Tensor,
+        atom_mask: torch.BoolTensor = None,
+        chain_idx: torch.Tensor = None,
+        chain_ids: List[str] = None,
+        seq: List[Dict[str, str]] = None,
+        residue_idx: torch.LongTensor = None,
+        device: Union[str, torch.device, None] = None,
+    ):
+        # reference protstruc.py:55-60
+        if (chain_idx is not None and chain_ids is None) or (chain_idx is None and chain_ids is not None):
+            raise ValueError("Both `chain_idx` and `chain_ids` should be provided or None.")
+
+        xyz = _always_tensor(xyz)
+        atom_mask = _always_tensor(atom_mask)
+        chain_idx = _always_tensor(chain_idx)
+        if xyz.ndim != 4 or xyz.shape[-1] != 3:
+            raise ValueError(f"xyz must have shape (batch, residues, atoms, 3), got {tuple(xyz.shape)}")
+
+        if device is None:
+            device = xyz.device if xyz.is_cuda else _default_device()
+        self.device = torch.device(device)
+
+        if chain_idx is not None:
+            # reference protstruc.py:75-80 -- checked on the host copy, before anything is launched
+            for i, chidx in enumerate(chain_idx):
+                valid = chidx[~torch.isnan(chidx)]
+                assert valid.numel() > 0 and valid.min() == 0, f"Protein {i}: Chain index should start from zero"
+
+        self.xyz = xyz.to(device=self.device, dtype=torch.float32).contiguous()
+        self.atom_mask = None if atom_mask is None else atom_mask.to(self.device)
+        self.batch_size, self.n_residues, self.max_n_atoms_per_residue = self.xyz.shape[:3]
+
+        if self.atom_mask is not None:
+            self.residue_mask = self.atom_mask.any(dim=-1)
+        else:
+            self.residue_mask = torch.ones(self.batch_size, self.n_residues, dtype=torch.bool, device=self.device)
+
+        if chain_idx is not None:
+            self.chain_idx = chain_idx.to(self.device)
+        else:
+            self.chain_idx = torch.zeros(self.batch_size, self.n_residues, device=self.device)
+
+        self.chain_ids = chain_ids
+        self.seq = seq
+        self.residue_idx = residue_idx
+        self._standardized = False
+        self._rng_state = None  # device int64 [seed, offset] of the diffusion sampler
+
+    # ------------------------------------------------------------------ constructors
+    @classmethod
+    def from_xyz(
+        cls,
+        xyz: Union[np.ndarray, torch.Tensor],
+        atom_mask: Union[np.ndarray, torch.Tensor] = None,
+        chain_idx: Union[np.ndarray, torch.Tensor] = None,
+        chain_ids: List[List[str]] = None,
+        seq: List[Dict[str, str]] = None,
+        **kwargs,
+    ) -> "StructureBatch":
+        """Reference protstruc.py:94-128."""
+        return cls(xyz, atom_mask, chain_idx, chain_ids, seq, **kwargs)
+
+    # ------------------------------------------------------------------ getters (protstruc.py:341-433)
+    def get_batch_size(self) -> int:
+        return self.batch_size
+
+    def get_xyz(self) -> torch.Tensor:
+        return self.xyz
+
+    def get_atom_mask(self) -> torch.BoolTensor:
+        return self.atom_mask
+
+    def get_residue_mask(self) -> torch.BoolTensor:
+        # Q5: the getter is the CA slot, not atom_mask.any(-1) (protstruc.py:378)
+        return self.atom_mask[:, :, ATOM.CA].bool()
+
+    def get_chain_idx(self) -> torch.LongTensor:
+        return self.chain_idx.long()
+
+    def get_chain_ids(self):
+        return self.chain_ids
+
+    def get_seq(self):
+        return self.seq
+
+    def get_total_lengths(self) -> torch.LongTensor:
+        return self.residue_mask.cumsum(dim=1).argmax(dim=1) + 1
+
+    def get_max_n_residues(self) -> int:
+        return self.n_residues
+
+    def get_max_n_atoms_per_residue(self) -> int:
+        return self.max_n_atoms_per_residue
+
+    # ------------------------------------------------------------------ A2 terminal masks
+    def get_n_terminal_mask(self) -> torch.BoolTensor:
+        """True at the first residue of each chain (protstruc.py:435-443)."""
+        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)[2]
+
+    def get_c_terminal_mask(self) -> torch.BoolTensor:
+        """True at the last residue of each chain (protstruc.py:445-453)."""
+        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)[3]
+
+    # ------------------------------------------------------------------ A1 pairwise distances
+    def pairwise_distance_matrix(self) -> Tuple[torch.FloatTensor, torch.BoolTensor]:
+        """All-atom distance between every pair of residues (protstruc.py:455-484).
+
+        Returns ``dist (B,N,N,A,A)`` fp32 and ``dist_mask`` of the same shape in
+        the dtype of ``atom_mask`` (bool normally).  The mask is not applied to
+        ``dist``."""
+        dist, dmask = ops.pairwise_distance(self.xyz, self.atom_mask)
+        if self.atom_mask is not None and self.atom_mask.dtype != torch.bool:
+            dmask = dmask.to(self.atom_mask.dtype)  # Q7: mask dtype follows atom_mask
+        return dist, dmask
+
+    # ------------------------------------------------------------------ A3 backbone dihedrals
+    def backbone_dihedrals(self) -> Tuple[torch.FloatTensor, torch.BoolTensor]:
+        """phi, psi, omega per residue and their validity mask (protstruc.py:486-541)."""
+        dih, dmask, _, _ = ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)
+        return dih, dmask
+
+    # ------------------------------------------------------------------ A4 / A5 frames
+    def backbone_orientations(self, a1: str = "N", a2: str = "CA", a3: str = "C") -> torch.FloatTensor:
+        """Gram-Schmidt frame of each residue, basis vectors as columns (protstruc.py:543-571)."""
+        s1, s2, s3 = ATOM[a1], ATOM[a2], ATOM[a3]  # KeyError on unknown names, as in the reference
+        return ops.frames(self.xyz, s1, s2, s3, want_trans=False)[0]
+
+    def backbone_translations(self, atom: str = "CA") -> torch.FloatTensor:
+        """Coordinates of one backbone atom per residue -- a view, as in the reference (protstruc.py:573-587)."""
+        return self.xyz[:, :, ATOM[atom]]
+
+    def backbone_orientations_and_translations(self, a1: str = "N", a2: str = "CA", a3: str = "C", atom: str = "CA"):
+        """Both frame outputs from one launch (rotation (B,N,3,3), translation (B,N,3), contiguous)."""
+        return ops.frames(self.xyz, ATOM[a1], ATOM[a2], ATOM[a3], ATOM[atom])
+
+    # ------------------------------------------------------------------ A6-A8 inter-residue angles
+    @staticmethod
+    def _pairwise_atom_slots(atoms_i: List[str], atoms_j: List[str]):
+        """Name validation of _pairwise_xyz (protstruc.py:603-608); the (B,N^2,n,3) gather itself is never built."""
+        for atom in atoms_i + atoms_j:
+            if not ATOM.is_valid(atom):
+                raise ValueError(f"Atom {atom} is not valid.")
+        return [int(ATOM[a]) for a in atoms_i], [int(ATOM[a]) for a in atoms_j]
+
+    def pairwise_dihedrals(self, atoms_i: List[str], atoms_j: List[str]) -> torch.FloatTensor:
+        """Dihedral of the four points (atoms_i of residue i ++ atoms_j of residue j) for all (i,j) (protstruc.py:620-640)."""
+        si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
+        return ops.pairwise_angles(self.xyz, si, sj, 4)
+
+    def pairwise_planar_angles(self, atoms_i: List[str], atoms_j: List[str]) -> torch.FloatTensor:
+        """Planar angle of the three points (protstruc.py:642-660)."""
+        si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
+        return ops.pairwise_angles(self.xyz, si, sj, 3)
+
+    def inter_residue_geometry(self) -> Dict[str, torch.Tensor]:
+        """trRosetta-style inter-residue features (protstruc.py:790-817)."""
+        ret = {}
+        dist, dist_mask = self.pairwise_distance_matrix()
+        ret["d_ca"] = dist[:, :, :, ATOM.CA, ATOM.CA]
+        ret["d_ca_mask"] = dist_mask[:, :, :, ATOM.CA, ATOM.CA]
+        ret["d_cb"] = dist[:, :, :, ATOM.CB, ATOM.CB]
+        ret["d_cb_mask"] = dist_mask[:, :, :, ATOM.CB, ATOM.CB]
+        ret["d_no"] = dist[:, :, :, ATOM.N, ATOM.O]
+        ret["d_no_mask"] = dist_mask[:, :, :, ATOM.N, ATOM.O]
+        ret["omega"] = self.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"])  # as coded at protstruc.py:811
+        ret["theta"] = self.pairwise_dihedrals(["N", "CA", "CB"], ["CB"])
+        ret["phi"] = self.pairwise_planar_angles(["CA", "CB"], ["CB"])
+        return ret
+
+    # ------------------------------------------------------------------ A9 standardize
+    def standardize(self, atom_mask: torch.BoolTensor = None, residue_mask: torch.BoolTensor = None):
+        """Per-structure, per-axis zero-mean / unit-std coordinates (protstruc.py:696-734)."""
+        if atom_mask is not None and residue_mask is not None:
+            raise ValueError("Only one of atom_mask and residue_mask can be specified.")
+        if self._standardized:
+            raise ValueError("Coordinates are already standardized.")
+        base = self.atom_mask
+        if atom_mask is not None:
+            m = atom_mask.to(self.device)
+            m = m if base is None else m * base
+        elif residue_mask is not None:
+            m = residue_mask.to(self.device).unsqueeze(-1)
+            m = m.expand(-1, -1, self.max_n_atoms_per_residue) if base is None else m * base
+        else:
+            m = base
+        self.mu, self.std = ops.standardize_(self.xyz, m)
+        self._standardized = True
+
+    def unstandardize(self):
+        """Undo ``standardize`` (protstruc.py:736-744)."""
+        if not self._standardized:
+            raise ValueError("Cannot unstandardize structures that are not standardized.")
+        ops.affine_(self.xyz, self.std, self.mu)
+        self._standardized = False
+
+    # ------------------------------------------------------------------ A10 diffusion
+    def manual_seed(self, seed: int) -> "StructureBatch":
+        """Seed the device sampler used by ``diffuse_xyz`` (Philox4x32-10, counter reset to 0)."""
+        self._rng_state = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+        return self
+
+    def diffuse_xyz(self, beta: torch.FloatTensor, noise: Optional[torch.Tensor] = None):
+        """One forward-diffusion step ``xyz <- sqrt(1-beta) xyz + sqrt(beta) eps`` (protstruc.py:864-878).
+
+        ``noise`` (optional, not in the reference) supplies ``eps`` explicitly;
+        by default it is drawn on the device."""
+        if noise is None and self._rng_state is None:
+            self.manual_seed(torch.initial_seed())
+        ops.diffuse_(self.xyz, beta.to(self.device), self._rng_state, None if noise is None else noise.to(self.device))

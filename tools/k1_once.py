@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Run the default K1 configuration a few times (profiling target for rocprofv3)."""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from protstruc_amd import _lib, ops
+
+B, N, A = 64, 512, 15
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for kv in sys.argv[2:]:
+    k, v = kv.split("=")
+    _lib.set_tuning(k, int(v))
+g = torch.Generator().manual_seed(0)
+xyz = torch.randn(B, N, A, 3, generator=g).cuda()
+mask = (torch.rand(B, N, A, generator=g) < 0.9)
+mask[:, :, :3] = True
+mask = mask.cuda()
+dist = torch.empty(B, N, N, A, A, device="cuda")
+dmask = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+for _ in range(reps):
+    ops.pairwise_distance(xyz, mask, out_dist=dist, out_mask=dmask)
+torch.cuda.synchronize()
+print("done")
