@@ -1,0 +1,73 @@
+"""Multi-GPU form of the pairwise-distance path: residue rows sharded over ranks.
+
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).
+``xyz`` / ``atom_mask`` are tiny (180 B per residue) and replicated on every
+rank; only the O(N^2) outputs are sharded.  Rank r computes residue rows
+[r*N/P, (r+1)*N/P) of every structure straight into its slice of a full-size
+(B, N, N, A, A) buffer -- no staging copy -- and, if ``gather`` is set, one
+all-gather per structure (a rank's slice of structure b is one contiguous run)
+reassembles the full matrix on every rank over xGMI.  The gather moves
+(P-1)/P of the whole result into every GPU and is bound by the xGMI links, not
+by the kernel; ``gather=False`` returns the row-sharded result,
+which is what a data-parallel consumer wants.
+
+The other kernels are per-residue / per-structure: they shard over the batch
+with no exchange ("replicas only").
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Balanced contiguous split of ``n_rows`` residue rows: rows [lo, hi) belong to ``rank``."""
+    return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
+
+
+def pairwise_distance_matrix_sharded(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
+                                     group=None, gather: bool = True,
+                                     out_dist: Optional[torch.Tensor] = None,
+                                     out_mask: Optional[torch.Tensor] = None):
+    """Row-sharded ``pairwise_distance_matrix``.
+
+    Returns ``(dist, dist_mask, (row_lo, row_hi))``.  With ``gather=True`` both
+    tensors are the full (B,N,N,A,A) result on every rank (bit-identical to the
+    single-GPU kernel); with ``gather=False`` only rows [row_lo,row_hi) of them
+    are defined on this rank."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    B, N, A = xyz.shape[:3]
+    lo, hi = shard_rows(N, rank, world)
+    shape = (B, N, N, A, A)
+    if out_dist is None:
+        out_dist = torch.empty(shape, dtype=torch.float32, device=xyz.device)
+    if out_mask is None:
+        out_mask = torch.empty(shape, dtype=torch.bool, device=xyz.device)
+    ops.pairwise_distance(xyz, atom_mask, row_begin=lo, row_end=hi, out_dist=out_dist, out_mask=out_mask)
+    if gather and world > 1:
+        _allgather_rows(out_dist, lo, hi, rank, world, group)
+        _allgather_rows(out_mask.view(torch.uint8), lo, hi, rank, world, group)
+    return out_dist, out_mask, (lo, hi)
+
+
+def _allgather_rows(full: torch.Tensor, lo: int, hi: int, rank: int, world: int, group) -> None:
+    """In-place all-gather of row slices of a (B, N, ...) tensor, one collective per structure."""
+    B, N = full.shape[:2]
+    even = (N % world == 0)
+    in_place = even and dist.get_backend(group) == "nccl"
+    for b in range(B):
+        mine = full[b, lo:hi]
+        if even:
+            # equal slices: rank r's rows sit at offset r * (N/world) of structure b -- the in-place
+            # layout ncclAllGather expects (sendbuff == recvbuff + rank * count)
+            dist.all_gather_into_tensor(full[b], mine if in_place else mine.clone(), group=group)
+        else:
+            for r in range(world):
+                rlo, rhi = shard_rows(N, r, world)
+                if rhi > rlo:
+                    dist.broadcast(full[b, rlo:rhi], src=dist.get_global_rank(group, r) if group else r, group=group)

@@ -1,0 +1,80 @@
+"""world_size-2 gloo test of the row-sharded pairwise-distance path (CPU).
+
+The HIP kernel cannot run here, so ``ops.pairwise_distance`` is replaced by a
+stand-in that fills the requested rows from the CPU oracle; what is under test
+is the sharding arithmetic and the gather, which are device-independent.
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _oracle_rows(xyz, atom_mask=None, *, row_begin=0, row_end=None, out_dist=None, out_mask=None, **kw):
+    from oracle import protstruc_oracle as O
+    d, m = O.pairwise_distance_matrix(xyz, atom_mask)
+    out_dist[:, row_begin:row_end] = d[:, row_begin:row_end]
+    out_mask[:, row_begin:row_end] = m[:, row_begin:row_end]
+    return out_dist, out_mask
+
+
+def _worker(rank, world, port, n_res, gather, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import protstruc_oracle as O
+        from protstruc_amd import distributed as D
+        from protstruc_amd import ops
+        ops.pairwise_distance = _oracle_rows
+        g = torch.Generator().manual_seed(5)
+        xyz = torch.randn(2, n_res, 15, 3, generator=g)
+        mask = torch.rand(2, n_res, 15, generator=g) < 0.8
+        nan = float("nan")
+        out_d = torch.full((2, n_res, n_res, 15, 15), nan)
+        out_m = torch.zeros(2, n_res, n_res, 15, 15, dtype=torch.bool)
+        d, m, (lo, hi) = D.pairwise_distance_matrix_sharded(xyz, mask, gather=gather, out_dist=out_d, out_mask=out_m)
+        rd, rm = O.pairwise_distance_matrix(xyz, mask)
+        assert (lo, hi) == D.shard_rows(n_res, rank, world)
+        if gather:
+            ok = torch.equal(d, rd) and torch.equal(m, rm)
+        else:
+            ok = torch.equal(d[:, lo:hi], rd[:, lo:hi]) and torch.equal(m[:, lo:hi], rm[:, lo:hi])
+            other = torch.ones(n_res, dtype=torch.bool)
+            other[lo:hi] = False
+            ok = ok and bool(torch.isnan(d[:, other]).all())  # nothing outside the shard was touched
+        q.put((rank, ok, lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_res,gather", [(8, True), (7, True), (8, False)])
+def test_row_sharded_distance_world2(n_res, gather):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + n_res + (100 if gather else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_res, gather, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert all(ok for _, ok, _, _ in got)
+    assert got[0][2] == 0 and got[0][3] == got[1][2] and got[1][3] == n_res  # shards tile [0, N)
+
+
+def test_shard_rows_partition():
+    from protstruc_amd.distributed import shard_rows
+    for n in (1, 7, 8, 512, 2048, 229):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [shard_rows(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
+            assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
