@@ -10,8 +10,10 @@
  * reference checkout.
  *
  * Conventions (all entry points):
- *   - every pointer is a DEVICE pointer owned by the caller; the library never
- *     allocates, frees or retains memory;
+ *   - every pointer is a DEVICE pointer owned by the caller (the only exception
+ *     are the two small `src` / `atom` descriptor arrays of K3, which are HOST
+ *     arrays read before the launch); the library never allocates, frees or
+ *     retains memory;
  *   - coordinates are contiguous fp32 `xyz[B][N][A][3]`; masks are contiguous
  *     one-byte booleans (0 / 1; any non-zero input byte counts as true);
  *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream);
@@ -38,7 +40,8 @@ const char* ps_error_string(int code);
 /*
  * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
  * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
- * "k1_variant" (0 = default).
+ * "k1_variant" (0 = pattern kernel on aligned shapes, 1 = slot-decode kernel), "k1_jt" (64/128),
+ * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values).
  * Not part of the drop-in surface; has no reference counterpart.
  */
 int ps_set_tuning(const char* key, int value);

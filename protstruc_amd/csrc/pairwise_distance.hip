@@ -39,6 +39,7 @@ struct K1Tuning {
     int rows_per_block = 1;   // IR
     int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
     int jt = 64;              // column residues per tile (64 or 128)
+    int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
 };
 K1Tuning g_k1;
 
@@ -310,7 +311,17 @@ __device__ __forceinline__ float4 lds_atom(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int JT, bool NT>
+// MATH: 0 = product arithmetic (correctly rounded sqrt, no contraction);
+//       1, 2 = timing experiments only (tools/k1_probe.py): raw v_sqrt_f32 / stores without any arithmetic.
+template <int MATH>
+__device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
+    if (MATH == 0) return dist_pp(p, q);
+    float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    return __builtin_amdgcn_sqrtf((sx + sy) + sz);
+}
+
+template <int JT, bool NT, int MATH>
 __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -385,13 +396,18 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             const float4* xj = sxj;
 #pragma unroll 4
             for (int g = 0; g < ngroups; ++g) {
-                const float4 q0 = lds_atom(xj + offj[0]), q1 = lds_atom(xj + offj[1]);
-                const float4 q2 = lds_atom(xj + offj[2]), q3 = lds_atom(xj + offj[3]);
                 uint4 u;
-                u.x = __float_as_uint(dist_pp(pi[0], q0));
-                u.y = __float_as_uint(dist_pp(pi[1], q1));
-                u.z = __float_as_uint(dist_pp(pi[2], q2));
-                u.w = __float_as_uint(dist_pp(pi[3], q3));
+                if (MATH == 2) {
+                    u = make_uint4(__float_as_uint(pi[0].x), __float_as_uint(pi[1].x), __float_as_uint(pi[2].x),
+                                   (unsigned)g);
+                } else {
+                    const float4 q0 = lds_atom(xj + offj[0]), q1 = lds_atom(xj + offj[1]);
+                    const float4 q2 = lds_atom(xj + offj[2]), q3 = lds_atom(xj + offj[3]);
+                    u.x = __float_as_uint(dist_pp_m<MATH>(pi[0], q0));
+                    u.y = __float_as_uint(dist_pp_m<MATH>(pi[1], q1));
+                    u.z = __float_as_uint(dist_pp_m<MATH>(pi[2], q2));
+                    u.w = __float_as_uint(dist_pp_m<MATH>(pi[3], q3));
+                }
                 store16<NT>(o, u);
                 o += 4 * AA15;
                 xj += 4 * RS;
@@ -479,12 +495,14 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
                        row_begin, row_end, out_rows, out_row_origin, IR)
     if (da && ma && g_k1.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
-        if (g_k1.store_nt)
-            hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, true>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N,
-                               row_begin, row_end, out_rows, out_row_origin, IR);
-        else
-            hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, false>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N,
-                               row_begin, row_end, out_rows, out_row_origin, IR);
+#define PS_K1_PAT(NT_, M_)                                                                                          \
+    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N, \
+                       row_begin, row_end, out_rows, out_row_origin, IR)
+        if (g_k1.math == 1) PS_K1_PAT(false, 1);
+        else if (g_k1.math == 2) PS_K1_PAT(false, 2);
+        else if (g_k1.store_nt) PS_K1_PAT(true, 0);
+        else PS_K1_PAT(false, 0);
+#undef PS_K1_PAT
     } else if (da && ma) {
         if (g_k1.store_nt) PS_K1_LAUNCH(true, true, true);
         else PS_K1_LAUNCH(false, true, true);
@@ -516,6 +534,11 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
+    if (!strcmp(key, "k1_math")) {
+        if (value < 0 || value > 2) return (int)hipErrorInvalidValue;
+        g_k1.math = value;
+        return 0;
+    }
     if (!strcmp(key, "k1_jt")) {
         if (value != 64 && value != 128) return (int)hipErrorInvalidValue;
         g_k1.jt = value;
@@ -529,6 +552,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_rows_per_block")) *value = g_k1.rows_per_block;
     else if (!strcmp(key, "k1_variant")) *value = g_k1.variant;
     else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
+    else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
