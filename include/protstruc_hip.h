@@ -31,6 +31,8 @@
 extern "C" {
 #endif
 
+#define PS_RNG_STATE_WORDS 528
+
 /* ABI version of this header (bumped on any signature change). */
 int ps_abi_version(void);
 
@@ -123,8 +125,11 @@ int ps_frames_f32(const float* xyz, float* rot, float* trans,
  * `n_per_struct` = N*A*3.  If `noise` is non-NULL it supplies eps (parity with
  * the reference's deterministic part); otherwise eps comes from Philox4x32-10 +
  * Box-Muller keyed by rng_state[0] (seed) at counter offset rng_state[1], and
- * rng_state[1] is advanced on the device after the draw so that a captured
- * graph replays with fresh noise.  rng_state is a device array of two uint64.
+ * rng_state[1] is advanced on the device by the last workgroup to finish, so that
+ * a captured graph replays with fresh noise without a second launch.  rng_state is
+ * a device array of PS_RNG_STATE_WORDS (528) uint64: word 0 = seed, word 1 =
+ * offset, the rest are completion tickets that must be zero when a call starts
+ * (the kernels leave them zero).
  */
 int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_struct,
                    uint64_t* rng_state, const float* noise, void* stream);
@@ -146,6 +151,44 @@ int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* s
  */
 int ps_affine_f32(float* xyz, const float* scale, const float* shift,
                   int B, int n_atoms_per_struct, void* stream);
+
+/*
+ * Fused step of the diffusion loop (BASELINE config 5): K5 followed by K4 on the
+ * freshly diffused coordinates in one launch -- replaces the pair of calls
+ * diffuse_xyz (protstruc.py:864-878) + backbone_orientations / backbone_translations
+ * (protstruc.py:543-587).  Arguments as K5 and K4; the noise stream is identical
+ * to the one ps_diffuse_f32 would draw from the same rng_state.
+ */
+int ps_diffuse_frames_f32(float* xyz, const float* beta, int B, int N, int A,
+                          uint64_t* rng_state, const float* noise,
+                          float* rot, float* trans, int a1, int a2, int a3, int t_atom,
+                          void* stream);
+
+/*
+ * The whole diffusion loop (BASELINE config 5) in one launch: T steps of
+ * ps_diffuse_frames_f32 with the coordinates resident in LDS between steps.
+ * betas is (T, B); rot (T,B,N,3,3), trans (T,B,N,3) and xyz_traj (T,B,N,A,3) are
+ * optional per-step outputs (NULL = not produced); xyz holds the final
+ * coordinates.  Bit-identical to T successive calls of ps_diffuse_frames_f32
+ * from the same rng_state (which ends up advanced by T).  rng_state is required.
+ */
+int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, int N, int A,
+                                uint64_t* rng_state, float* rot, float* trans, float* xyz_traj,
+                                int a1, int a2, int a3, int t_atom, void* stream);
+
+/*
+ * Fused trRosetta featuriser -- replaces StructureBatch.inter_residue_geometry
+ * (protstruc.py:790-817) without materialising the (B,N,N,A,A) tensor: writes
+ * six (B,N,N) fp32 planes d_ca, d_cb, d_no (slices [CA,CA], [CB,CB], [N,O] of
+ * K1's dist), omega = dihedral(CA_i,CB_i,CA_j,CB_j), theta =
+ * dihedral(N_i,CA_i,CB_i,CB_j), phi = angle(CA_i,CB_i,CB_j), and the three
+ * (B,N,N) u8 mask planes.  atom_mask may be NULL (all present).  Needs A >= 5.
+ */
+int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
+                                  float* d_ca, float* d_cb, float* d_no,
+                                  float* omega, float* theta, float* phi,
+                                  uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask,
+                                  int B, int N, int A, void* stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,12 @@ SIGNATURES = {
     "ps_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_stream]),
     "ps_diffuse_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, ctypes.c_void_p, _c_f32p, _c_stream]),
+    "ps_diffuse_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p,
+                                       _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_diffusion_trajectory_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_f32p,
+                                             _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_inter_residue_geometry_f32": (_c_int, [_c_f32p, _c_u8p] + [_c_f32p] * 6 + [_c_u8p] * 3 + [_c_int, _c_int, _c_int,
+                                                                                                  _c_stream]),
     "ps_standardize_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),
     "ps_affine_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_stream]),
 }

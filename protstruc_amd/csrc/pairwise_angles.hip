@@ -52,6 +52,48 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     }
 }
 
+// Fused trRosetta featuriser (reference protstruc.py:790-817): the three atom-pair planes of K1 that
+// inter_residue_geometry slices out (CA-CA, CB-CB, N-O), their masks, and the three K3 features, in
+// one sweep -- 27 bytes written per residue pair instead of 1125.  Same lane layout as K3.
+__global__ __launch_bounds__(256) void k3_inter_residue_geometry(
+    const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
+    float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
+    float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
+    int A, int IR) {
+    const int b = blockIdx.z;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int i0 = blockIdx.y * IR, i1 = min(i0 + IR, N);
+    const bool live = j < N;
+    const int jc = live ? j : N - 1;
+    const float* sj = xyz + ((size_t)b * N + jc) * (size_t)A * 3;
+    const f3 ca_j = load3(sj + 3), o_j = load3(sj + 9), cb_j = load3(sj + 12);
+    uint8_t mj_ca = 1, mj_o = 1, mj_cb = 1;
+    if (amask) {
+        const uint8_t* mj = amask + ((size_t)b * N + jc) * A;
+        mj_ca = mj[1] != 0; mj_o = mj[3] != 0; mj_cb = mj[4] != 0;
+    }
+    for (int i = i0; i < i1; ++i) {
+        const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
+        const f3 n_i = load3(si), ca_i = load3(si + 3), cb_i = load3(si + 12);
+        uint8_t mi_n = 1, mi_ca = 1, mi_cb = 1;
+        if (amask) {
+            const uint8_t* mi = amask + ((size_t)b * N + i) * A;
+            mi_n = mi[0] != 0; mi_ca = mi[1] != 0; mi_cb = mi[4] != 0;
+        }
+        if (!live) continue;
+        const size_t o = ((size_t)b * N + i) * N + j;
+        d_ca[o] = dist3(ca_i, ca_j);
+        d_cb[o] = dist3(cb_i, cb_j);
+        d_no[o] = dist3(n_i, o_j);
+        m_ca[o] = mi_ca & mj_ca;
+        m_cb[o] = mi_cb & mj_cb;
+        m_no[o] = mi_n & mj_o;
+        omega[o] = dihedral4(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
+        theta[o] = dihedral4(n_i, ca_i, cb_i, cb_j);
+        phi[o] = angle3(ca_i, cb_i, cb_j);
+    }
+}
+
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
            int out_rows, int out_row_origin, hipStream_t s) {
@@ -98,4 +140,20 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
             srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
     return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
                                                out_row_origin, s);
+}
+
+extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb,
+                                             float* d_no, float* omega, float* theta, float* phi, uint8_t* d_ca_mask,
+                                             uint8_t* d_cb_mask, uint8_t* d_no_mask, int B, int N, int A,
+                                             void* stream) {
+    if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
+        return (int)hipErrorInvalidValue;
+    if (B < 0 || N < 0 || A < 5 || B > 65535) return (int)hipErrorInvalidValue;
+    if (B == 0 || N == 0) return 0;
+    const int IR = 16;
+    if ((N + IR - 1) / IR > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k3_inter_residue_geometry, dim3((N + 255) / 256, (N + IR - 1) / IR, B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
+                       d_ca_mask, d_cb_mask, d_no_mask, N, A, IR);
+    return ps_check_launch();
 }

@@ -40,6 +40,7 @@ struct K1Tuning {
     int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
     int jt = 64;              // column residues per tile (64 or 128)
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
+    int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
 };
 K1Tuning g_k1;
 
@@ -52,24 +53,6 @@ __device__ __forceinline__ void store16(void* p, uint4 v) {
         __builtin_nontemporal_store(w, reinterpret_cast<u32x4_t*>(p));
     else
         *reinterpret_cast<u32x4_t*>(p) = w;
-}
-
-// Correctly rounded sqrt for x >= 0 without the subnormal pre-scaling of the
-// library routine: v_sqrt_f32 is within 1 ulp, so the answer is s-1ulp, s or
-// s+1ulp and two exact fma residuals pick it.  0, inf and NaN fall through
-// unchanged (every comparison with a NaN residual is false).  A squared
-// distance below 1.2e-38 (atoms closer than 1e-19) would lose correct rounding,
-// nothing else.
-__device__ __forceinline__ float sqrt_rn_pos(float x) {
-    const float s = __builtin_amdgcn_sqrtf(x);
-    const float lo = __uint_as_float(__float_as_uint(s) - 1u);
-    const float hi = __uint_as_float(__float_as_uint(s) + 1u);
-    const float r_lo = __builtin_fmaf(-lo, s, x);
-    const float r_hi = __builtin_fmaf(-hi, s, x);
-    float r = s;
-    r = (r_lo <= 0.0f) ? lo : r;
-    r = (r_hi > 0.0f) ? hi : r;
-    return r;
 }
 
 __device__ __forceinline__ float dist_pp(float4 p, float4 q) {
@@ -321,7 +304,7 @@ __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
     return __builtin_amdgcn_sqrtf((sx + sy) + sz);
 }
 
-template <int JT, bool NT, int MATH>
+template <int JT, bool NT, int MATH, bool UNROLL>
 __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -394,23 +377,28 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             for (int k = 0; k < 4; ++k) pi[k] = sxi[il * RS + ai[k]];
             float* o = dist + (row0 + (size_t)il * N) * AA15 + 4u * tid;
             const float4* xj = sxj;
-#pragma unroll 4
-            for (int g = 0; g < ngroups; ++g) {
+            auto group = [&](int g) {
                 uint4 u;
                 if (MATH == 2) {
                     u = make_uint4(__float_as_uint(pi[0].x), __float_as_uint(pi[1].x), __float_as_uint(pi[2].x),
                                    (unsigned)g);
                 } else {
-                    const float4 q0 = lds_atom(xj + offj[0]), q1 = lds_atom(xj + offj[1]);
-                    const float4 q2 = lds_atom(xj + offj[2]), q3 = lds_atom(xj + offj[3]);
+                    const float4* x = xj + g * (4 * RS);
+                    const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
+                    const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
                     u.x = __float_as_uint(dist_pp_m<MATH>(pi[0], q0));
                     u.y = __float_as_uint(dist_pp_m<MATH>(pi[1], q1));
                     u.z = __float_as_uint(dist_pp_m<MATH>(pi[2], q2));
                     u.w = __float_as_uint(dist_pp_m<MATH>(pi[3], q3));
                 }
-                store16<NT>(o, u);
-                o += 4 * AA15;
-                xj += 4 * RS;
+                store16<NT>(o + (size_t)g * (4 * AA15), u);
+            };
+            if (UNROLL && ngroups == JT / 4) {  // full tile: straight-line code, stores issued back to back
+#pragma unroll
+                for (int g = 0; g < JT / 4; ++g) group(g);
+            } else {
+#pragma unroll 4
+                for (int g = 0; g < ngroups; ++g) group(g);
             }
         }
     }
@@ -495,13 +483,15 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
                        row_begin, row_end, out_rows, out_row_origin, IR)
     if (da && ma && g_k1.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
-#define PS_K1_PAT(NT_, M_)                                                                                          \
-    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, N, \
-                       row_begin, row_end, out_rows, out_row_origin, IR)
-        if (g_k1.math == 1) PS_K1_PAT(false, 1);
-        else if (g_k1.math == 2) PS_K1_PAT(false, 2);
-        else if (g_k1.store_nt) PS_K1_PAT(true, 0);
-        else PS_K1_PAT(false, 0);
+#define PS_K1_PAT(NT_, M_, U_)                                                                                     \
+    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, \
+                       N, row_begin, row_end, out_rows, out_row_origin, IR)
+        if (g_k1.math == 1) PS_K1_PAT(false, 1, false);
+        else if (g_k1.math == 2 && g_k1.unroll) PS_K1_PAT(false, 2, true);
+        else if (g_k1.math == 2) PS_K1_PAT(false, 2, false);
+        else if (g_k1.store_nt) PS_K1_PAT(true, 0, false);
+        else if (g_k1.unroll) PS_K1_PAT(false, 0, true);
+        else PS_K1_PAT(false, 0, false);
 #undef PS_K1_PAT
     } else if (da && ma) {
         if (g_k1.store_nt) PS_K1_LAUNCH(true, true, true);
@@ -534,6 +524,10 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
+    if (!strcmp(key, "k1_unroll")) {
+        g_k1.unroll = value ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "k1_math")) {
         if (value < 0 || value > 2) return (int)hipErrorInvalidValue;
         g_k1.math = value;
@@ -553,6 +547,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_variant")) *value = g_k1.variant;
     else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
+    else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else return (int)hipErrorInvalidValue;
     return 0;
 }

@@ -29,6 +29,31 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) {
     return ((0.0f + px) + py) + pz;
 }
 
+// Correctly rounded sqrt for x >= 0 without the subnormal pre-scaling of the
+// library routine: v_sqrt_f32 is within 1 ulp, so the answer is s-1ulp, s or
+// s+1ulp and two exact fma residuals pick it.  0, inf and NaN fall through
+// unchanged (every comparison with a NaN residual is false).  A squared
+// distance below 1.2e-38 (atoms closer than 1e-19) would lose correct rounding,
+// nothing else.
+__device__ __forceinline__ float sqrt_rn_pos(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __uint_as_float(__float_as_uint(s) - 1u);
+    const float hi = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_lo = __builtin_fmaf(-lo, s, x);
+    const float r_hi = __builtin_fmaf(-hi, s, x);
+    float r = s;
+    r = (r_lo <= 0.0f) ? lo : r;
+    r = (r_hi > 0.0f) ? hi : r;
+    return r;
+}
+
+// |a - b| exactly as K1 evaluates it (protstruc.py:477-479): differences, squares, two adds, sqrt
+__device__ __forceinline__ float dist3(f3 a, f3 b) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    return sqrt_rn_pos((sx + sy) + sz);
+}
+
 // x.norm(dim=-1) (geometry.py:29-31); sqrtf is the correctly rounded one
 __device__ __forceinline__ float norm3(f3 a) { return sqrtf(dot3(a, a)); }
 

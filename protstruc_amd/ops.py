@@ -16,6 +16,9 @@ import torch
 from . import _lib
 
 
+RNG_STATE_WORDS = 528  # PS_RNG_STATE_WORDS of include/protstruc_hip.h
+
+
 def _require_device(t: torch.Tensor, name: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -125,6 +128,27 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
     return out
 
 
+def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None):
+    """Fused featuriser: dict of six (B,N,N) fp32 planes and three (B,N,N) bool planes."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    if A < 5:
+        raise IndexError("inter_residue_geometry needs the N, CA, C, O, CB atom slots")
+    m = _u8c(atom_mask, "atom_mask")
+    dev = xyz.device
+    fkeys = ["d_ca", "d_cb", "d_no", "omega", "theta", "phi"]
+    mkeys = ["d_ca_mask", "d_cb_mask", "d_no_mask"]
+    with torch.cuda.device(dev):
+        f = torch.empty(6, B, N, N, dtype=torch.float32, device=dev)
+        k = torch.empty(3, B, N, N, dtype=torch.bool, device=dev)
+        rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[_ptr(f[i]) for i in range(6)],
+                                                       *[_ptr(k[i]) for i in range(3)], B, N, A, _stream(xyz))
+    _lib.check(rc, "ps_inter_residue_geometry_f32")
+    out = {name: f[i] for i, name in enumerate(fkeys)}
+    out.update({name: k[i] for i, name in enumerate(mkeys)})
+    return out
+
+
 def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, want_rot: bool = True,
            want_trans: bool = True):
     """K4.  Returns (rot (B,N,3,3) or None, trans (B,N,3) or None)."""
@@ -142,7 +166,8 @@ def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, wan
 
 def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Tensor] = None,
              noise: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K5, in place on a contiguous fp32 ``xyz``.  ``rng_state``: int64 device tensor [seed, offset]."""
+    """K5, in place on a contiguous fp32 ``xyz``.  ``rng_state``: int64 device tensor of RNG_STATE_WORDS
+    words, [0] = seed, [1] = draw offset, the rest zero."""
     _require_device(xyz, "xyz")
     if xyz.dtype != torch.float32 or not xyz.is_contiguous():
         raise ValueError("diffuse_ needs a contiguous float32 xyz (it is updated in place)")
@@ -157,10 +182,64 @@ def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Te
             raise ValueError("noise must have the shape of xyz")
     elif rng_state is None:
         raise ValueError("either rng_state or noise is required")
+    if rng_state is not None and (rng_state.numel() < RNG_STATE_WORDS or rng_state.dtype != torch.int64):
+        raise ValueError(f"rng_state must be an int64 tensor of {RNG_STATE_WORDS} words")
     with torch.cuda.device(xyz.device):
         rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
     _lib.check(rc, "ps_diffuse_f32")
     return xyz
+
+
+def diffuse_frames_(xyz: torch.Tensor, beta: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1,
+                    rng_state: Optional[torch.Tensor] = None, noise: Optional[torch.Tensor] = None,
+                    out_rot: Optional[torch.Tensor] = None, out_trans: Optional[torch.Tensor] = None):
+    """Fused K5 + K4: diffuse ``xyz`` in place and return the frames of the new coordinates."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("diffuse_frames_ needs a contiguous float32 xyz (it is updated in place)")
+    B, N, A = xyz.shape[:3]
+    beta = _f32c(beta, "beta")
+    if beta.shape != (B,):
+        raise ValueError(f"beta must have shape ({B},), got {tuple(beta.shape)}")
+    if noise is not None:
+        noise = _f32c(noise, "noise")
+    elif rng_state is None:
+        raise ValueError("either rng_state or noise is required")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        rot = out_rot if out_rot is not None else torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev)
+        trans = out_trans if out_trans is not None else torch.empty(B, N, 3, dtype=torch.float32, device=dev)
+        rc = _lib.load().ps_diffuse_frames_f32(_ptr(xyz), _ptr(beta), B, N, A, _ptr(rng_state), _ptr(noise), _ptr(rot),
+                                               _ptr(trans), int(a1), int(a2), int(a3), int(t_atom), _stream(xyz))
+    _lib.check(rc, "ps_diffuse_frames_f32")
+    return rot, trans
+
+
+def diffusion_trajectory_(xyz: torch.Tensor, betas: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int,
+                          rng_state: torch.Tensor, want_rot: bool = True, want_trans: bool = True,
+                          want_xyz: bool = False):
+    """K55: T diffusion steps in one launch, coordinates resident in LDS.  ``betas``: (T, B).
+    Returns (rot (T,B,N,3,3) | None, trans (T,B,N,3) | None, xyz_traj (T,B,N,A,3) | None); ``xyz`` ends as step T."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("diffusion_trajectory_ needs a contiguous float32 xyz (it is updated in place)")
+    B, N, A = xyz.shape[:3]
+    betas = _f32c(betas, "betas")
+    if betas.ndim != 2 or betas.shape[1] != B:
+        raise ValueError(f"betas must have shape (T, {B}), got {tuple(betas.shape)}")
+    T = betas.shape[0]
+    if rng_state is None or rng_state.numel() < RNG_STATE_WORDS or rng_state.dtype != torch.int64:
+        raise ValueError(f"rng_state must be an int64 tensor of {RNG_STATE_WORDS} words")
+    dev = xyz.device
+    with torch.cuda.device(dev):
+        rot = torch.empty(T, B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None
+        trans = torch.empty(T, B, N, 3, dtype=torch.float32, device=dev) if want_trans else None
+        traj = torch.empty(T, B, N, A, 3, dtype=torch.float32, device=dev) if want_xyz else None
+        rc = _lib.load().ps_diffusion_trajectory_f32(_ptr(xyz), _ptr(betas), T, B, N, A, _ptr(rng_state), _ptr(rot),
+                                                     _ptr(trans), _ptr(traj), int(a1), int(a2), int(a3), int(t_atom),
+                                                     _stream(xyz))
+    _lib.check(rc, "ps_diffusion_trajectory_f32")
+    return rot, trans, traj
 
 
 def standardize_(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor]):

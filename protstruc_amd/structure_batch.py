@@ -204,18 +204,12 @@ class StructureBatch:
 
     def inter_residue_geometry(self) -> Dict[str, torch.Tensor]:
         """trRosetta-style inter-residue features (protstruc.py:790-817)."""
-        ret = {}
-        dist, dist_mask = self.pairwise_distance_matrix()
-        ret["d_ca"] = dist[:, :, :, ATOM.CA, ATOM.CA]
-        ret["d_ca_mask"] = dist_mask[:, :, :, ATOM.CA, ATOM.CA]
-        ret["d_cb"] = dist[:, :, :, ATOM.CB, ATOM.CB]
-        ret["d_cb_mask"] = dist_mask[:, :, :, ATOM.CB, ATOM.CB]
-        ret["d_no"] = dist[:, :, :, ATOM.N, ATOM.O]
-        ret["d_no_mask"] = dist_mask[:, :, :, ATOM.N, ATOM.O]
-        ret["omega"] = self.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"])  # as coded at protstruc.py:811
-        ret["theta"] = self.pairwise_dihedrals(["N", "CA", "CB"], ["CB"])
-        ret["phi"] = self.pairwise_planar_angles(["CA", "CB"], ["CB"])
-        return ret
+        g = ops.inter_residue_geometry(self.xyz, self.atom_mask)  # one fused launch, no (B,N,N,A,A) tensor
+        if self.atom_mask is not None and self.atom_mask.dtype != torch.bool:
+            for k in ("d_ca_mask", "d_cb_mask", "d_no_mask"):
+                g[k] = g[k].to(self.atom_mask.dtype)
+        order = ["d_ca", "d_ca_mask", "d_cb", "d_cb_mask", "d_no", "d_no_mask", "omega", "theta", "phi"]
+        return {k: g[k] for k in order}
 
     # ------------------------------------------------------------------ A9 standardize
     def standardize(self, atom_mask: torch.BoolTensor = None, residue_mask: torch.BoolTensor = None):
@@ -246,7 +240,10 @@ class StructureBatch:
     # ------------------------------------------------------------------ A10 diffusion
     def manual_seed(self, seed: int) -> "StructureBatch":
         """Seed the device sampler used by ``diffuse_xyz`` (Philox4x32-10, counter reset to 0)."""
-        self._rng_state = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+        # layout of ps_diffuse_f32's rng_state: word 0 seed, word 1 draw offset, rest zeroed tickets
+        state = torch.zeros(ops.RNG_STATE_WORDS, dtype=torch.int64)
+        state[0] = int(seed) & 0x7FFFFFFFFFFFFFFF
+        self._rng_state = state.to(self.device)
         return self
 
     def diffuse_xyz(self, beta: torch.FloatTensor, noise: Optional[torch.Tensor] = None):
@@ -257,3 +254,28 @@ class StructureBatch:
         if noise is None and self._rng_state is None:
             self.manual_seed(torch.initial_seed())
         ops.diffuse_(self.xyz, beta.to(self.device), self._rng_state, None if noise is None else noise.to(self.device))
+
+    def diffuse_xyz_and_frames(self, beta: torch.FloatTensor, a1: str = "N", a2: str = "CA", a3: str = "C",
+                               atom: str = "CA", noise: Optional[torch.Tensor] = None, out_rot=None, out_trans=None):
+        """One diffusion step fused with the frame computation of the new coordinates (one launch):
+        equivalent to ``diffuse_xyz(beta)`` followed by ``backbone_orientations(a1, a2, a3)`` and a
+        contiguous ``backbone_translations(atom)``; draws the same noise as ``diffuse_xyz`` would."""
+        if noise is None and self._rng_state is None:
+            self.manual_seed(torch.initial_seed())
+        return ops.diffuse_frames_(self.xyz, beta.to(self.device), ATOM[a1], ATOM[a2], ATOM[a3], ATOM[atom],
+                                   self._rng_state, None if noise is None else noise.to(self.device),
+                                   out_rot=out_rot, out_trans=out_trans)
+
+    def diffuse_trajectory(self, betas: torch.FloatTensor, a1: str = "N", a2: str = "CA", a3: str = "C",
+                           atom: str = "CA", want_orientations: bool = True, want_translations: bool = True,
+                           want_xyz: bool = False):
+        """The diffusion loop ``for t: diffuse_xyz(betas[t]); backbone_orientations()`` as ONE launch.
+
+        ``betas`` has shape (T, B).  The coordinates stay in on-chip LDS between steps; only the
+        per-step outputs that are asked for are written: orientations (T,B,N,3,3), translations
+        (T,B,N,3), coordinates (T,B,N,A,3).  The result is bit-identical to T calls of
+        ``diffuse_xyz_and_frames`` and ``get_xyz()`` ends at step T."""
+        if self._rng_state is None:
+            self.manual_seed(torch.initial_seed())
+        return ops.diffusion_trajectory_(self.xyz, betas.to(self.device), ATOM[a1], ATOM[a2], ATOM[a3], ATOM[atom],
+                                         self._rng_state, want_orientations, want_translations, want_xyz)

@@ -447,6 +447,66 @@ def test_inter_residue_geometry_golden(SB):
             assert_close(v, g[k], bad_frac=1.0 / g[k].numel())
 
 
+def test_inter_residue_geometry_matches_unfused_kernels(SB):
+    """The fused featuriser must equal the K1 slices and the K3 calls it replaces, bit for bit."""
+    xyz, mask = synth(77, 3, 100)
+    sb = SB.from_xyz(xyz, mask)
+    geo = sb.inter_residue_geometry()
+    d, m = sb.pairwise_distance_matrix()
+    for key, (a, c) in {"d_ca": (1, 1), "d_cb": (4, 4), "d_no": (0, 3)}.items():
+        assert torch.equal(geo[key], d[:, :, :, a, c]) and torch.equal(geo[key + "_mask"], m[:, :, :, a, c])
+
+    def same(x, y):
+        return torch.equal(x.isnan(), y.isnan()) and torch.equal(x.nan_to_num(0), y.nan_to_num(0))
+
+    assert same(geo["omega"], sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]))
+    assert same(geo["theta"], sb.pairwise_dihedrals(["N", "CA", "CB"], ["CB"]))
+    assert same(geo["phi"], sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
+    fm = SB.from_xyz(xyz, mask.float()).inter_residue_geometry()
+    assert fm["d_ca_mask"].dtype == torch.float32 and torch.equal(fm["d_ca_mask"].bool(), geo["d_ca_mask"])
+
+
+def test_fused_diffuse_frames(SB):
+    xyz, mask = synth(88, 5, 37)
+    beta = torch.tensor([0.01, 0.2, 0.5, 0.9, 0.999])
+    noise = torch.randn(5, 37, 15, 3, generator=torch.Generator().manual_seed(3))
+    a = SB.from_xyz(xyz.clone(), mask)
+    a.diffuse_xyz(beta, noise=noise)
+    ra, ta = a.backbone_orientations_and_translations()
+    b = SB.from_xyz(xyz.clone(), mask)
+    rb, tb = b.diffuse_xyz_and_frames(beta, noise=noise)
+    assert torch.equal(a.get_xyz(), b.get_xyz()) and torch.equal(ra, rb) and torch.equal(ta, tb)
+    # sampler path: same seed -> the fused step draws exactly the noise of the unfused one
+    c = SB.from_xyz(xyz.clone(), mask).manual_seed(42)
+    d = SB.from_xyz(xyz.clone(), mask).manual_seed(42)
+    for _ in range(3):
+        c.diffuse_xyz(beta)
+        rc = c.backbone_orientations()
+        rd, td = d.diffuse_xyz_and_frames(beta)
+        assert torch.equal(c.get_xyz(), d.get_xyz()) and torch.equal(rc, rd)
+        assert torch.equal(td, d.get_xyz()[:, :, 1])
+    assert_close(rd, O.backbone_orientations(d.get_xyz().cpu()), bad_frac=1e-3)
+
+
+@pytest.mark.parametrize("B,N,T", [(2, 37, 5), (3, 130, 4), (1, 7, 3)])
+def test_diffusion_trajectory_equals_stepwise(SB, B, N, T):
+    """The LDS-resident loop kernel must equal T fused steps bit for bit (same Philox stream)."""
+    xyz, mask = synth(99 + N, B, N)
+    betas = torch.rand(T, B, generator=torch.Generator().manual_seed(N)) * 0.5 + 0.01
+    a = SB.from_xyz(xyz.clone(), mask).manual_seed(5)
+    rots, trs, xs = [], [], []
+    for t in range(T):
+        r, tr = a.diffuse_xyz_and_frames(betas[t])
+        rots.append(r); trs.append(tr); xs.append(a.get_xyz().clone())
+    b = SB.from_xyz(xyz.clone(), mask).manual_seed(5)
+    rot, trans, traj = b.diffuse_trajectory(betas, want_xyz=True)
+    assert torch.equal(rot, torch.stack(rots)) and torch.equal(trans, torch.stack(trs))
+    assert torch.equal(traj, torch.stack(xs)) and torch.equal(b.get_xyz(), a.get_xyz())
+    # the sampler state advanced by T in both: the next draw agrees as well
+    a.diffuse_xyz(betas[0]); b.diffuse_xyz(betas[0])
+    assert torch.equal(a.get_xyz(), b.get_xyz())
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")
