@@ -120,6 +120,15 @@ int ps_frames_f32(const float* xyz, float* rot, float* trans,
                   void* stream);
 
 /*
+ * Point-wise geometry primitives -- replace the free functions geometry.angle,
+ * geometry.dihedral and geometry.gram_schmidt (geometry.py:39-124, :413-439) on
+ * (n,3) point arrays:  mode 0: out[n] = angle(a,b,c);  mode 1: out[n] =
+ * dihedral(a,b,c,d);  mode 2: out[n][3][3] = gram_schmidt(a,b,c).  Radians.
+ */
+int ps_pointwise_f32(int mode, const float* a, const float* b, const float* c, const float* d,
+                     float* out, long long n, void* stream);
+
+/*
  * K5 -- replaces StructureBatch.diffuse_xyz (protstruc.py:864-878), in place:
  *   xyz[b] <- sqrt(1 - beta[b]) * xyz[b] + sqrt(beta[b]) * eps,  eps ~ N(0,1) iid.
  * `n_per_struct` = N*A*3.  If `noise` is non-NULL it supplies eps (parity with

@@ -28,6 +28,7 @@ SIGNATURES = {
                                         ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_stream]),
+    "ps_pointwise_f32": (_c_int, [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_longlong, _c_stream]),
     "ps_diffuse_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, ctypes.c_void_p, _c_f32p, _c_stream]),
     "ps_diffuse_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_f32p, _c_f32p, _c_f32p,
                                        _c_int, _c_int, _c_int, _c_int, _c_stream]),

@@ -28,7 +28,40 @@ __global__ __launch_bounds__(256) void k4_frames(const float* __restrict__ xyz, 
     }
 }
 
+// Point-wise forms of the geometry primitives for the free functions of protstruc.geometry
+// (reference geometry.py:39-124, :413-439): a, b, c(, d) are (n,3) arrays.
+//   mode 0: out[n]   = angle(a, b, c)        mode 1: out[n] = dihedral(a, b, c, d)
+//   mode 2: out[n*9] = gram_schmidt(a, b, c) (3x3 row-major, basis vectors as columns)
+__global__ __launch_bounds__(256) void k_pointwise(const float* __restrict__ a, const float* __restrict__ b,
+                                                   const float* __restrict__ c, const float* __restrict__ d,
+                                                   float* __restrict__ out, size_t n, int mode) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const f3 pa = load3(a + i * 3), pb = load3(b + i * 3), pc = load3(c + i * 3);
+    if (mode == 0) {
+        out[i] = angle3(pa, pb, pc);
+    } else if (mode == 1) {
+        out[i] = dihedral4(pa, pb, pc, load3(d + i * 3));
+    } else {
+        f3 e1, e2, e3;
+        gram_schmidt3(pa, pb, pc, e1, e2, e3);
+        float* o = out + i * 9;
+        o[0] = e1.x; o[1] = e2.x; o[2] = e3.x;
+        o[3] = e1.y; o[4] = e2.y; o[5] = e3.y;
+        o[6] = e1.z; o[7] = e2.z; o[8] = e3.z;
+    }
+}
+
 }  // namespace
+
+extern "C" int ps_pointwise_f32(int mode, const float* a, const float* b, const float* c, const float* d, float* out,
+                                long long n, void* stream) {
+    if (mode < 0 || mode > 2 || !a || !b || !c || !out || n < 0 || (mode == 1 && !d)) return (int)hipErrorInvalidValue;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, b, c, d, out, (size_t)n, mode);
+    return ps_check_launch();
+}
 
 extern "C" int ps_frames_f32(const float* xyz, float* rot, float* trans, int B, int N, int A, int a1, int a2, int a3,
                              int t_atom, void* stream) {

@@ -149,6 +149,24 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
     return out
 
 
+def pointwise(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, d: Optional[torch.Tensor] = None):
+    """angle (mode 0) / dihedral (1) / gram_schmidt (2) over broadcast (*,3) point tensors."""
+    pts = [a, b, c] + ([d] if d is not None else [])
+    pts = torch.broadcast_tensors(*[_f32c(p, "points") for p in pts])
+    shape = pts[0].shape[:-1]
+    if pts[0].shape[-1] != 3:
+        raise ValueError("points must have a trailing axis of size 3")
+    flat = [p.reshape(-1, 3).contiguous() for p in pts]
+    n = flat[0].shape[0]
+    dev = flat[0].device
+    with torch.cuda.device(dev):
+        out = torch.empty((n, 9) if mode == 2 else (n,), dtype=torch.float32, device=dev)
+        rc = _lib.load().ps_pointwise_f32(mode, _ptr(flat[0]), _ptr(flat[1]), _ptr(flat[2]),
+                                          _ptr(flat[3]) if mode == 1 else None, _ptr(out), n, _stream(flat[0]))
+    _lib.check(rc, "ps_pointwise_f32")
+    return out.reshape(*shape, 3, 3) if mode == 2 else out.reshape(shape)
+
+
 def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, want_rot: bool = True,
            want_trans: bool = True):
     """K4.  Returns (rot (B,N,3,3) or None, trans (B,N,3) or None)."""

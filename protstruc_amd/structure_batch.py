@@ -110,6 +110,17 @@ class StructureBatch:
         """Reference protstruc.py:94-128."""
         return cls(xyz, atom_mask, chain_idx, chain_ids, seq, **kwargs)
 
+    @classmethod
+    def from_pdb(cls, pdb_path: Union[str, List[str]], **kwargs) -> "StructureBatch":
+        """Initialize from one PDB file or a list of them (reference protstruc.py:131-193).
+
+        Parsing is host-side plumbing (``protstruc_amd/pdb.py``); the padded batch is then moved to the GPU."""
+        from . import pdb as _pdb
+
+        paths = pdb_path if isinstance(pdb_path, list) else [pdb_path]
+        xyz, mask, chain_idx, chain_ids, seq, residue_idx = _pdb.read_batch(paths)
+        return cls(xyz, mask, chain_idx, chain_ids, seq, residue_idx, **kwargs)
+
     # ------------------------------------------------------------------ getters (protstruc.py:341-433)
     def get_batch_size(self) -> int:
         return self.batch_size

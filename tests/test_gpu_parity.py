@@ -507,6 +507,70 @@ def test_diffusion_trajectory_equals_stepwise(SB, B, N, T):
     assert torch.equal(a.get_xyz(), b.get_xyz())
 
 
+# ----------------------------------------------------------------------------- config 1 + free functions
+def test_config1_from_pdb_15c8(SB):
+    """BASELINE config 1: StructureBatch.from_pdb('15c8_HL.pdb').pairwise_distance_matrix() (B=1, N=229)."""
+    import os
+    from tests.conftest import GOLDEN_DIR
+    g = load_golden("g10_config1_15c8_HL")
+    sb = SB.from_pdb(os.path.join(GOLDEN_DIR, "15c8_HL.pdb"))
+    assert sb.get_max_n_residues() == int(g["n_residues"]) == 229
+    assert int(sb.get_atom_mask().sum()) == int(g["atom_count"])
+    d, m = sb.pairwise_distance_matrix()
+    assert d.shape == (1, 229, 229, 15, 15)
+
+    def ulp_close(got, want, k=2):   # protein scale: 1 ulp at 60 A is 3.8e-6 -- gate at k ulp, NaNs identical
+        got = got.cpu()
+        assert torch.equal(got.isnan(), want.isnan())
+        tol = k * torch.finfo(torch.float32).eps * want.abs().clamp_min(1.0)
+        assert ((got - want).abs().nan_to_num(0) <= tol.nan_to_num(1)).all()
+
+    ulp_close(d[0, :, :, 1, 1], g["ca_ca"])
+    ulp_close(d[0, :, :, 4, 4], g["cb_cb"])
+    assert torch.equal(m[0, :, :, 1, 1].cpu(), g["ca_ca_mask"]) and torch.equal(m[0, :, :, 4, 4].cpu(), g["cb_cb_mask"])
+    bi, bj = g["block_i"].cuda(), g["block_j"].cuda()
+    ulp_close(d[0, bi, bj], g["blocks"])
+    assert torch.equal(m[0, bi, bj].cpu(), g["blocks_mask"])
+    # reference tests/test_StructureBatch.py:43-66: two chains -> two N- and two C-termini
+    assert torch.equal(sb.get_n_terminal_mask().cpu(), g["nterm"]) and int(g["nterm"].sum()) == 2
+    assert torch.equal(sb.get_c_terminal_mask().cpu(), g["cterm"]) and int(g["cterm"].sum()) == 2
+    dih, dmask = sb.backbone_dihedrals()
+    assert_close(dih, g["dihedrals"])
+    assert torch.equal(dmask.cpu(), g["dihedral_mask"])
+    assert_close(sb.backbone_orientations(), g["rot"], tol=2e-5)
+    multi = SB.from_pdb([os.path.join(GOLDEN_DIR, n) for n in ("15c8_HL.pdb", "1ad0_DC.pdb", "6dc4.pdb")])
+    assert len(multi.get_xyz()) == 3
+    assert (multi.get_n_terminal_mask().sum(1) == 2).all() and (multi.get_c_terminal_mask().sum(1) == 2).all()
+
+
+def test_geometry_free_functions(SB):
+    import protstruc_amd.geometry as geom
+    g = load_golden("g9_primitives")
+    a, b, c, d, c60 = g["a"], g["b"], g["c"], g["d"], g["c60"]
+    # analytic answers of the reference's tests/test_geometry.py:35-190, tensor and numpy flavours
+    assert torch.allclose(geom.angle(a, b, c, to_degree=True).cpu(), torch.tensor([90.0]))
+    assert torch.allclose(geom.angle(a, b, c60, to_degree=True).cpu(), torch.tensor([60.0]), atol=1e-4)
+    assert torch.allclose(geom.dihedral(a, b, c, d, to_degree=True).cpu(), torch.tensor([-90.0]))
+    out = geom.dihedral(a.numpy(), b.numpy(), c.numpy(), d.numpy(), to_degree=True)
+    assert isinstance(out, np.ndarray) and out.shape == (1,) and np.allclose(out, [-90.0])
+    assert isinstance(geom.angle(a.numpy().astype(np.float64), b.numpy(), c.numpy()), np.ndarray)
+    assert geom.dihedral(a[None], b[None], c[None], d[None]).shape == (1, 1)
+    assert geom.dot(torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4.0, 5.0, 6.0])).item() == 32.0
+    assert abs(geom.norm(np.array([1.0, 2.0, 3.0])).item() - 14 ** 0.5) < 1e-6
+    P = g["P"]
+    assert_close(geom.angle(P[0], P[1], P[2]), g["rnd_angle"])
+    assert_close(geom.dihedral(P[0], P[1], P[2], P[3]), g["rnd_dihedral"])
+    assert_close(geom.dot(P[0], P[1]), g["rnd_dot"])
+    assert_close(geom.norm(P[0]), g["rnd_norm"])
+    assert_close(geom.unit(P[0]), g["rnd_unit"])
+    assert_close(geom.gram_schmidt(P[0], P[1], P[2]), g["rnd_frame"])
+    frame = geom.gram_schmidt(torch.randn(16, 30, 3), torch.randn(16, 30, 3), torch.randn(16, 30, 3))
+    assert frame.shape == (16, 30, 3, 3)
+    ideal = load_golden("g5_frames")["ideal_xyz"]
+    eye = geom.gram_schmidt(ideal[:, :, 0], ideal[:, :, 1], ideal[:, :, 2]).cpu()
+    assert (eye == torch.eye(3).expand(2, 10, -1, -1)).all()
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")

@@ -175,6 +175,24 @@ def main():
     geo = SB.from_xyz(xyz, mask).inter_residue_geometry()
     save("g8_inter_residue_geometry", xyz=xyz, atom_mask=mask, **geo)
 
+    # G10 BASELINE config 1: 15c8_HL.pdb parsed by the BUILD's reader (biotite is absent, so the reference's own
+    # parser cannot run), then the reference's from_xyz(...) featurisers on those tensors
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from protstruc_amd.pdb import read_batch
+    pxyz, pmask, pchain, pchain_ids, pseq, _ = read_batch([os.path.join(args.out, "15c8_HL.pdb")])
+    sb = SB.from_xyz(pxyz, pmask, chain_idx=pchain, chain_ids=pchain_ids)
+    d, m = sb.pairwise_distance_matrix()
+    g = torch.Generator().manual_seed(101)
+    n = pxyz.shape[1]
+    bi = torch.randint(0, n, (600,), generator=g)
+    bj = torch.randint(0, n, (600,), generator=g)
+    dih, dih_mask = sb.backbone_dihedrals()
+    save("g10_config1_15c8_HL", n_residues=torch.tensor(n), atom_count=pmask.sum(),
+         ca_ca=d[0, :, :, 1, 1], cb_cb=d[0, :, :, 4, 4], ca_ca_mask=m[0, :, :, 1, 1], cb_cb_mask=m[0, :, :, 4, 4],
+         block_i=bi, block_j=bj, blocks=d[0, bi, bj], blocks_mask=m[0, bi, bj],
+         dihedrals=dih, dihedral_mask=dih_mask, nterm=sb.get_n_terminal_mask(), cterm=sb.get_c_terminal_mask(),
+         rot=sb.backbone_orientations(), chain_idx=pchain)
+
     # G9 free-function known answers, evaluated by the reference ---------------------------
     a = torch.tensor([[1.0, 0.0, 0.0]])
     b = torch.tensor([[0.0, 0.0, 0.0]])
