@@ -93,7 +93,7 @@ def load_traffic():
     return None
 
 
-def rowshard_allgather(dev, rank, world, steps=3):
+def rowshard_allgather(dev, rank, world, max_over_ranks, steps=3):
     """North-star config 4 in miniature: residue-sharded K1 into a full-size buffer + RCCL all-gather."""
     import torch.distributed as dist
     from protstruc_amd.distributed import pairwise_distance_matrix_sharded
@@ -114,9 +114,8 @@ def rowshard_allgather(dev, rank, world, steps=3):
             pairwise_distance_matrix_sharded(xyz, mask, gather=gather, out_dist=out_d, out_mask=out_m)
         torch.cuda.synchronize(dev)
         dist.barrier()
-        dt = torch.tensor([(time.perf_counter() - t0) / steps], device=dev)
-        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-        res["kernel_plus_allgather_ms" if gather else "kernel_only_ms"] = dt.item() * 1e3
+        dt = max_over_ranks([(time.perf_counter() - t0) / steps])[0]
+        res["kernel_plus_allgather_ms" if gather else "kernel_only_ms"] = dt * 1e3
     pairs = b * n * n
     res.update({
         "workload": f"B={b}, N_res={n}, rows sharded over {world} ranks",
@@ -135,6 +134,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowshard", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -147,14 +147,26 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
 
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > n_dev:
+        raise SystemExit(f"{world} ranks but only {n_dev} GPUs visible (RCCL needs one GPU per rank)")
+    dev = torch.device("cuda", local_rank % n_dev)  # ranks share a GPU only in gloo rehearsals
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
+        kw = {"device_id": dev} if args.backend == "nccl" else {}
+        dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=300), **kw)
+
+    def max_over_ranks(values):
+        """Element-wise max of a list of floats over all ranks (object collective: works on any backend)."""
+        if not dist:
+            return values
+        gathered = [None] * world
+        dist.all_gather_object(gathered, values)
+        return [max(v[i] for v in gathered) for i in range(len(values))]
 
     from protstruc_amd import _lib, ops
 
@@ -186,12 +198,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
-    if dist:
-        t = torch.tensor([elapsed, kernel_ms], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms_max = t[0].item(), t[1].item()
-    else:
-        kernel_ms_max = kernel_ms
+    elapsed, kernel_ms_max = max_over_ranks([elapsed, kernel_ms])
 
     pairs_per_step = B * N_RES * N_RES * world
     value = pairs_per_step * args.steps / elapsed
@@ -237,7 +244,7 @@ def main():
         del out_d, out_m
         torch.cuda.empty_cache()
         try:
-            result["rowshard_allgather"] = rowshard_allgather(dev, rank, world)
+            result["rowshard_allgather"] = rowshard_allgather(dev, rank, world, max_over_ranks)
         except Exception as exc:  # noqa: BLE001 -- report, do not lose the main measurement
             result["rowshard_allgather"] = {"error": f"{type(exc).__name__}: {exc}"}
     emit()

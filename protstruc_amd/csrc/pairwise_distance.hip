@@ -41,6 +41,7 @@ struct K1Tuning {
     int jt = 64;              // column residues per tile (64 or 128)
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
+    int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
 };
 K1Tuning g_k1;
 
@@ -482,7 +483,8 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     hipLaunchKernelGGL((k1_pairdist_a15<JT, NT_, DA_, MA_>), grid, dim3(256), lds, s, xyz, amask, dist, dmask, N,    \
                        row_begin, row_end, out_rows, out_row_origin, IR)
     if (da && ma && g_k1.variant == 0) {
-        const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
+        const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
+                               (size_t)g_k1.lds_pad_kb * 1024;
 #define PS_K1_PAT(NT_, M_, U_)                                                                                     \
     hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, \
                        N, row_begin, row_end, out_rows, out_row_origin, IR)
@@ -524,6 +526,11 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
+    if (!strcmp(key, "k1_lds_pad_kb")) {
+        if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
+        g_k1.lds_pad_kb = value;
+        return 0;
+    }
     if (!strcmp(key, "k1_unroll")) {
         g_k1.unroll = value ? 1 : 0;
         return 0;
@@ -548,6 +555,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
+    else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
