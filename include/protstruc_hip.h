@@ -199,6 +199,28 @@ int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
                                   uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask,
                                   int B, int N, int A, void* stream);
 
+/*
+ * Rigid-body ops.  ps_rigid_f32 replaces StructureBatch.translate,
+ * rotate, center_at and get_local_xyz (protstruc.py:662-694, :759-788, :347-362):
+ *   out = R x + t   (transpose = 0)   or   out = R^T x + t   (transpose = 1)
+ * r_mode: 0 none, 1 one shared 3x3, 2 per structure (B,3,3), 3 per residue (B,N,3,3);
+ * t_mode: 0 none, 1 one shared (3), 2 per structure (B,3), 3 per residue (B,N,3),
+ *         4 per atom (B,N,A,3).  xyz_out may alias xyz_in.
+ */
+int ps_rigid_f32(const float* xyz_in, float* xyz_out, const float* R, int r_mode, int transpose,
+                 const float* t, int t_mode, int B, int N, int A, void* stream);
+
+/* Replaces StructureBatch.center_of_mass (protstruc.py:746-757): com[b] = nanmean over residues of xyz[b][:][atom]. */
+int ps_center_of_mass_f32(const float* xyz, float* com, int B, int N, int A, int atom, void* stream);
+
+/*
+ * Replaces the coordinate construction of StructureBatch.from_backbone_orientations_translations
+ * (protstruc.py:289-312): xyz[b][n][a] = rot[b][n] * ideal[a] + trans[b][n] for a < n_ideal, 0 for
+ * the remaining slots.  ideal is a device array (n_ideal, 3).
+ */
+int ps_frames_to_backbone_f32(const float* rot, const float* trans, const float* ideal, int n_ideal,
+                              float* xyz, int B, int N, int A, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

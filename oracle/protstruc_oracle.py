@@ -280,3 +280,70 @@ def diffuse_xyz(xyz: torch.Tensor, beta: torch.Tensor, noise: torch.Tensor) -> t
     beta = beta.reshape(-1, 1, 1, 1)
     scaled = noise * beta.sqrt()
     return (1 - beta).sqrt() * xyz + scaled
+
+
+# --------------------------------------------------------------------------
+# N3  rigid-body ops            reference: protstruc.py:347-362, :662-694, :746-788, :264-319
+# --------------------------------------------------------------------------
+def translate(xyz: torch.Tensor, translation: torch.Tensor, atomwise: bool = False) -> torch.Tensor:
+    if not atomwise:
+        translation = translation.unsqueeze(-2)  # "b n c -> b n () c"
+    return xyz + translation
+
+
+def rotate(xyz: torch.Tensor, rotation: torch.Tensor) -> torch.Tensor:
+    """x <- R x; rotation (B,3,3) per structure or (3,3) shared (einsum "bnaij,bnaj->bnai")."""
+    if rotation.ndim == 2:
+        rotation = rotation[None, None, None]
+    else:
+        rotation = rotation[:, None, None]
+    return torch.einsum("bnaij,bnaj->bnai", rotation.expand(*xyz.shape[:3], 3, 3), xyz)
+
+
+def center_of_mass(xyz: torch.Tensor) -> torch.Tensor:
+    """nanmean of the CA slot over residues (CA only, as the reference)."""
+    return xyz[:, :, CA_SLOT].nanmean(dim=1)
+
+
+def center_at(xyz: torch.Tensor, center: torch.Tensor = None) -> torch.Tensor:
+    if center is None:
+        center = torch.zeros(1, 3)
+    if center.ndim == 1:
+        center = center.unsqueeze(0)
+    translation = center - center_of_mass(xyz)
+    return xyz + translation[:, None, None, :]
+
+
+def get_local_xyz(xyz: torch.Tensor) -> torch.Tensor:
+    """R^T x minus the GLOBAL CA position of the residue (the reference subtracts after rotating)."""
+    n_atoms = xyz.shape[2]
+    rot = backbone_orientations(xyz)[:, :, None].expand(-1, -1, n_atoms, -1, -1)
+    local = torch.einsum("bnaji,bnaj->bnai", rot, xyz)
+    return local - xyz[:, :, CA_SLOT].unsqueeze(-2)
+
+
+def ideal_backbone(include_cb: bool = False) -> torch.Tensor:
+    """(3 or 4, 3) ideal N, CA, C[, CB] with CA at the origin and C on +x (reference geometry.py:191-226,
+    constants/ideal.py: N-CA 1.458, CA-C 1.523, angle N-CA-C 1.937 rad)."""
+    import math
+    ca = torch.zeros(3)
+    c = torch.tensor([1.523, 0.0, 0.0])
+    n = torch.tensor([1.458 * math.cos(1.937), 1.458 * math.sin(1.937), 0.0])
+    atoms = [n, ca, c]
+    if include_cb:
+        b_, c_ = ca - n, c - ca
+        a_ = torch.linalg.cross(b_, c_)
+        atoms.append(-0.58273431 * a_ + 0.56802827 * b_ - 0.54067466 * c_ + ca)
+    return torch.stack(atoms)
+
+
+def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, include_cb: bool = False, n_slots: int = 15):
+    """xyz (B,N,15,3) = rot @ ideal + trans for the first 3/4 slots, zeros after; float mask of ones/zeros."""
+    ideal = ideal_backbone(include_cb)
+    n_atoms = ideal.shape[0]
+    B, N = rot.shape[:2]
+    placed = torch.einsum("bnaij,bnaj->bnai", rot[:, :, None].expand(-1, -1, n_atoms, -1, -1),
+                          ideal.expand(B, N, -1, -1)) + trans[:, :, None, :]
+    xyz = torch.cat([placed, torch.zeros(B, N, n_slots - n_atoms, 3)], dim=-2)
+    mask = torch.cat([torch.ones(B, N, n_atoms), torch.zeros(B, N, n_slots - n_atoms)], dim=-1)
+    return xyz, mask

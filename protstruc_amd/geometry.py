@@ -16,6 +16,26 @@ import torch
 from . import ops
 
 
+# ideal backbone geometry (reference constants/ideal.py:2-36): bond lengths in Angstrom, angles in radians
+IDEAL_NA, IDEAL_AC, IDEAL_NAC = 1.458, 1.523, 1.937
+
+
+def ideal_backbone_coordinates(size, include_cb: bool = False) -> torch.Tensor:
+    """Ideal N, CA, C (and CB) coordinates with CA at the origin and CA->C along +x, expanded to
+    ``(*size, 3 or 4, 3)`` (reference geometry.py:191-226).  Returned on the CPU like the reference."""
+    import math
+
+    ca = torch.zeros(3)
+    c = torch.tensor([IDEAL_AC, 0.0, 0.0])
+    n = torch.tensor([IDEAL_NA * math.cos(IDEAL_NAC), IDEAL_NA * math.sin(IDEAL_NAC), 0.0])
+    atoms = [n, ca, c]
+    if include_cb:
+        b_, c_ = ca - n, c - ca
+        a_ = torch.linalg.cross(b_, c_)
+        atoms.append(-0.58273431 * a_ + 0.56802827 * b_ - 0.54067466 * c_ + ca)  # tetrahedral CB placement
+    return torch.stack(atoms).expand(*size, -1, -1)
+
+
 def _device():
     if not torch.cuda.is_available():
         raise RuntimeError("protstruc_amd.geometry is HIP-only (no CPU fallback): no GPU is visible")

@@ -289,3 +289,67 @@ def affine_(xyz: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torc
         rc = _lib.load().ps_affine_f32(_ptr(xyz), _ptr(scale), _ptr(shift), B, n_atoms, _stream(xyz))
     _lib.check(rc, "ps_affine_f32")
     return xyz
+
+
+def rigid(xyz: torch.Tensor, R: Optional[torch.Tensor] = None, t: Optional[torch.Tensor] = None, *,
+          transpose: bool = False, inplace: bool = False) -> torch.Tensor:
+    """x' = R x + t (or R^T x + t).  R: (3,3) | (B,3,3) | (B,N,3,3);  t: (3,) | (B,3) | (B,N,3) | (B,1,3) | (B,N,A,3)."""
+    _require_device(xyz, "xyz")
+    if xyz.dtype != torch.float32 or not xyz.is_contiguous():
+        raise ValueError("rigid needs a contiguous float32 xyz")
+    B, N, A = xyz.shape[:3]
+    r_mode = t_mode = 0
+    if R is not None:
+        R = _f32c(R, "rotation")
+        r_mode = {2: 1, 3: 2, 4: 3}.get(R.ndim, -1)
+        ok = R.shape[-2:] == (3, 3) and (r_mode == 1 or (R.shape[0] == B and (r_mode == 2 or R.shape[1] == N)))
+        if r_mode < 0 or not ok:
+            raise ValueError(f"rotation must be (3,3), ({B},3,3) or ({B},{N},3,3), got {tuple(R.shape)}")
+    if t is not None:
+        t = _f32c(t, "translation")
+        if t.shape == (3,):
+            t_mode = 1
+        elif t.shape == (B, 3) or t.shape == (B, 1, 3):
+            t_mode = 2
+        elif t.shape == (B, N, 3):
+            t_mode = 3
+        elif t.shape == (B, N, A, 3):
+            t_mode = 4
+        elif t.shape == (1, 3):
+            t, t_mode = t.reshape(3), 1
+        else:
+            raise ValueError(f"translation shape {tuple(t.shape)} does not broadcast against xyz {tuple(xyz.shape)}")
+        t = t.contiguous()
+    with torch.cuda.device(xyz.device):
+        out = xyz if inplace else torch.empty_like(xyz)
+        rc = _lib.load().ps_rigid_f32(_ptr(xyz), _ptr(out), _ptr(R), r_mode, int(transpose), _ptr(t), t_mode, B, N, A,
+                                      _stream(xyz))
+    _lib.check(rc, "ps_rigid_f32")
+    return out
+
+
+def center_of_mass(xyz: torch.Tensor, atom: int = 1) -> torch.Tensor:
+    """(B,3) nanmean over residues of one atom slot."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    with torch.cuda.device(xyz.device):
+        com = torch.empty(B, 3, dtype=torch.float32, device=xyz.device)
+        rc = _lib.load().ps_center_of_mass_f32(_ptr(xyz), _ptr(com), B, N, A, int(atom), _stream(xyz))
+    _lib.check(rc, "ps_center_of_mass_f32")
+    return com
+
+
+def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, ideal: torch.Tensor, n_slots: int) -> torch.Tensor:
+    """(B,N,n_slots,3): rot @ ideal[a] + trans for the first len(ideal) slots, zeros after."""
+    rot = _f32c(rot, "orientations")
+    trans = _f32c(trans, "translations")
+    B, N = rot.shape[:2]
+    if rot.shape != (B, N, 3, 3) or trans.shape != (B, N, 3):
+        raise ValueError("orientations must be (B,N,3,3) and translations (B,N,3)")
+    ideal = _f32c(ideal.to(rot.device), "ideal")
+    with torch.cuda.device(rot.device):
+        xyz = torch.empty(B, N, n_slots, 3, dtype=torch.float32, device=rot.device)
+        rc = _lib.load().ps_frames_to_backbone_f32(_ptr(rot), _ptr(trans), _ptr(ideal), ideal.shape[0], _ptr(xyz), B, N,
+                                                   n_slots, _stream(rot))
+    _lib.check(rc, "ps_frames_to_backbone_f32")
+    return xyz

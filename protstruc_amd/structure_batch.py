@@ -121,12 +121,46 @@ class StructureBatch:
         xyz, mask, chain_idx, chain_ids, seq, residue_idx = _pdb.read_batch(paths)
         return cls(xyz, mask, chain_idx, chain_ids, seq, residue_idx, **kwargs)
 
+    @classmethod
+    def from_backbone_orientations_translations(
+        cls,
+        orientations: Union[np.ndarray, torch.Tensor],
+        translations: Union[np.ndarray, torch.Tensor],
+        chain_idx: Union[np.ndarray, torch.Tensor] = None,
+        chain_ids: List[List[str]] = None,
+        seq: List[Dict[str, str]] = None,
+        residue_idx: Union[np.ndarray, torch.Tensor] = None,
+        include_cb: bool = False,
+        **kwargs,
+    ) -> "StructureBatch":
+        """Ideal backbone (N, CA, C[, CB]) placed by per-residue frames (reference protstruc.py:264-319).
+        The atom mask is float32 ones / zeros, as in the reference."""
+        from .general import MAX_N_ATOMS_PER_RESIDUE
+        from .geometry import ideal_backbone_coordinates
+
+        orientations, translations = _always_tensor(orientations), _always_tensor(translations)
+        dev = kwargs.get("device") or (orientations.device if orientations.is_cuda else _default_device())
+        ideal = ideal_backbone_coordinates((), include_cb)  # (3 or 4, 3)
+        n_atoms = ideal.shape[0]
+        xyz = ops.frames_to_backbone(orientations.to(dev), translations.to(dev), ideal, MAX_N_ATOMS_PER_RESIDUE)
+        B, N = xyz.shape[:2]
+        atom_mask = torch.zeros(B, N, MAX_N_ATOMS_PER_RESIDUE, device=xyz.device)
+        atom_mask[:, :, :n_atoms] = 1.0
+        return cls(xyz, atom_mask, chain_idx, chain_ids, seq, residue_idx, **kwargs)
+
     # ------------------------------------------------------------------ getters (protstruc.py:341-433)
     def get_batch_size(self) -> int:
         return self.batch_size
 
     def get_xyz(self) -> torch.Tensor:
         return self.xyz
+
+    def get_local_xyz(self) -> torch.Tensor:
+        """Atoms in the local frame of their residue: R^T x minus the (global) CA position, exactly as the
+        reference computes it (protstruc.py:347-362)."""
+        rot = self.backbone_orientations()
+        ca = self.xyz[:, :, ATOM.CA].contiguous()
+        return ops.rigid(self.xyz, rot, -ca, transpose=True)
 
     def get_atom_mask(self) -> torch.BoolTensor:
         return self.atom_mask
@@ -221,6 +255,35 @@ class StructureBatch:
                 g[k] = g[k].to(self.atom_mask.dtype)
         order = ["d_ca", "d_ca_mask", "d_cb", "d_cb_mask", "d_no", "d_no_mask", "omega", "theta", "phi"]
         return {k: g[k] for k in order}
+
+    # ------------------------------------------------------------------ rigid-body ops
+    def translate(self, translation: torch.Tensor, atomwise: bool = False):
+        """In-place translation by (B,N,3) / (B,1,3), or (B,N,A,3) with ``atomwise`` (protstruc.py:662-679)."""
+        translation = translation.to(self.device)
+        want = 4 if atomwise else 3
+        if translation.ndim != want:
+            raise ValueError(f"translation must have {want} dimensions, got {translation.ndim}")
+        ops.rigid(self.xyz, None, translation, inplace=True)
+
+    def rotate(self, rotation: torch.Tensor):
+        """x <- R x with R (B,3,3) per structure or (3,3) shared (protstruc.py:681-694)."""
+        self.xyz = ops.rigid(self.xyz, rotation.to(self.device), None)
+
+    def center_of_mass(self) -> torch.Tensor:
+        """(B,3) mean CA position ignoring NaNs (protstruc.py:746-757)."""
+        return ops.center_of_mass(self.xyz, ATOM.CA)
+
+    def center_at(self, center: torch.Tensor = None):
+        """Translate so that the CA centre sits at ``center`` ((B,3) or (3,); origin by default) (protstruc.py:759-788)."""
+        if center is None:
+            center = torch.zeros(1, 3)
+        if center.ndim > 2 or center.shape[-1] != 3:
+            raise ValueError(f"`center` must have a shape of (batch_size, 3) or (3,), got {center.shape}.")
+        if center.ndim == 2 and center.shape[0] != self.batch_size and not (center.shape[0] == 1):
+            raise ValueError(f"`center` must have a shape of (batch_size, 3) or (3,), got {center.shape}.")
+        center = center.to(self.device, torch.float32).reshape(-1, 3)
+        translation = center - self.center_of_mass()          # (B,3) by broadcasting
+        ops.rigid(self.xyz, None, translation.contiguous(), inplace=True)
 
     # ------------------------------------------------------------------ A9 standardize
     def standardize(self, atom_mask: torch.BoolTensor = None, residue_mask: torch.BoolTensor = None):

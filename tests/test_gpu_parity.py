@@ -571,6 +571,43 @@ def test_geometry_free_functions(SB):
     assert (eye == torch.eye(3).expand(2, 10, -1, -1)).all()
 
 
+def test_rigid_body_ops_golden(SB):
+    g = load_golden("g11_rigid_ops")
+    xyz, mask = g["xyz"], g["atom_mask"]
+    T = 1e-5 * 3   # coordinates at 5-15 A scale: one fp32 ulp is ~1e-6, matrix products round differently
+
+    def fresh():
+        return SB.from_xyz(xyz.clone(), mask)
+
+    sb = fresh(); sb.translate(g["t_res"]); assert_close(sb.get_xyz(), g["translate_res"], tol=T)
+    sb = fresh(); sb.translate(g["t_b"]); assert_close(sb.get_xyz(), g["translate_b"], tol=T)
+    sb = fresh(); sb.translate(g["t_atom"], atomwise=True); assert_close(sb.get_xyz(), g["translate_atom"], tol=T)
+    sb = fresh(); sb.rotate(g["R_b"]); assert_close(sb.get_xyz(), g["rotate_b"], tol=T)
+    sb = fresh(); sb.rotate(g["R_b"][0]); assert_close(sb.get_xyz(), g["rotate_shared"], tol=T)
+    assert_close(fresh().center_of_mass(), g["com"], tol=T)
+    sb = SB.from_xyz(xyz[:1].clone(), mask[:1]); sb.center_at(); assert_close(sb.get_xyz(), g["center_origin_b1"], tol=T)
+    sb = fresh(); sb.center_at(g["centers"]); assert_close(sb.get_xyz(), g["center_b"], tol=T)
+    # reference tests/test_StructureBatch.py:258-275: the CA centre lands on the requested point
+    assert torch.allclose(sb.center_of_mass().cpu(), g["centers"], rtol=1e-4, atol=1e-5)
+    sb = fresh(); sb.center_at(g["centers"][0]); assert_close(sb.get_xyz(), g["center_shared"], tol=T)
+    sb = fresh(); sb.center_at(); assert torch.allclose(sb.center_of_mass().cpu(), torch.zeros(4, 3), atol=1e-5)
+    with pytest.raises(ValueError):
+        fresh().center_at(torch.zeros(2, 3, 3))
+    sb2 = SB.from_xyz(g["xyz2"])
+    assert_close(sb2.get_local_xyz(), g["local_xyz"], tol=T, bad_frac=1e-3)
+    rot, tr = sb2.backbone_orientations(), sb2.backbone_translations()
+    for cb in (0, 1):
+        sb3 = SB.from_backbone_orientations_translations(rot, tr, include_cb=bool(cb))
+        assert sb3.get_max_n_atoms_per_residue() == 15
+        assert_close(sb3.get_xyz(), g[f"bb_xyz_cb{cb}"], tol=T, bad_frac=1e-3)
+        assert sb3.get_atom_mask().dtype == torch.float32 and torch.equal(sb3.get_atom_mask().cpu(), g[f"bb_mask_cb{cb}"])
+        # round trip: frames of the rebuilt backbone are the frames it was built from
+        assert_close(sb3.backbone_orientations(), rot.cpu(), tol=T, bad_frac=1e-2)
+    import protstruc_amd.geometry as geom
+    assert torch.equal(geom.ideal_backbone_coordinates((), True), g["ideal4"])
+    assert geom.ideal_backbone_coordinates((16, 30)).shape == (16, 30, 3, 3)
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")

@@ -166,3 +166,24 @@ def test_primitives_known_answers():
     close(O.norm(P[0]), g["rnd_norm"])
     close(O.unit(P[0]), g["rnd_unit"])
     close(O.gram_schmidt(P[0], P[1], P[2]), g["rnd_frame"])
+
+
+def test_rigid_body_ops():
+    g = load_golden("g11_rigid_ops")
+    xyz = g["xyz"]
+    close(O.translate(xyz, g["t_res"]), g["translate_res"])
+    close(O.translate(xyz, g["t_b"]), g["translate_b"])
+    close(O.translate(xyz, g["t_atom"], atomwise=True), g["translate_atom"])
+    close(O.rotate(xyz, g["R_b"]), g["rotate_b"], tol=5e-6)
+    close(O.rotate(xyz, g["R_b"][0]), g["rotate_shared"], tol=5e-6)
+    close(O.center_of_mass(xyz), g["com"])
+    close(O.center_at(xyz[:1]), g["center_origin_b1"], tol=5e-6)
+    close(O.center_at(xyz, g["centers"]), g["center_b"], tol=5e-6)
+    close(O.center_at(xyz, g["centers"][0]), g["center_shared"], tol=5e-6)
+    close(O.get_local_xyz(g["xyz2"]), g["local_xyz"], tol=5e-6)
+    assert torch.equal(O.ideal_backbone(False), g["ideal3"]) and torch.equal(O.ideal_backbone(True), g["ideal4"])
+    rot, tr = O.backbone_orientations(g["xyz2"]), O.backbone_translations(g["xyz2"])
+    for cb in (0, 1):
+        x, m = O.frames_to_backbone(rot, tr, include_cb=bool(cb))
+        close(x, g[f"bb_xyz_cb{cb}"], tol=5e-6)
+        assert m.dtype == g[f"bb_mask_cb{cb}"].dtype and torch.equal(m, g[f"bb_mask_cb{cb}"])

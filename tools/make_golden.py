@@ -193,6 +193,39 @@ def main():
          dihedrals=dih, dihedral_mask=dih_mask, nterm=sb.get_n_terminal_mask(), cterm=sb.get_c_terminal_mask(),
          rot=sb.backbone_orientations(), chain_idx=pchain)
 
+    # G11 rigid-body ops
+    xyz, mask = synth(111, 4, 20, scale=5.0)
+    xyz[1, 3, :] = float("nan")  # a residue without coordinates: nanmean must skip it
+    g = torch.Generator().manual_seed(112)
+    q, _ = torch.linalg.qr(torch.randn(4, 3, 3, generator=g))
+    t_res = torch.randn(4, 20, 3, generator=g)
+    t_b = torch.randn(4, 1, 3, generator=g)
+    t_atom = torch.randn(4, 20, 15, 3, generator=g)
+    centers = torch.randn(4, 3, generator=g)
+    out = {"xyz": xyz, "atom_mask": mask, "R_b": q, "t_res": t_res, "t_b": t_b, "t_atom": t_atom, "centers": centers}
+    sb = SB.from_xyz(xyz.clone(), mask); sb.translate(t_res); out["translate_res"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.translate(t_b); out["translate_b"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.translate(t_atom, atomwise=True); out["translate_atom"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.rotate(q); out["rotate_b"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.rotate(q[0]); out["rotate_shared"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); out["com"] = sb.center_of_mass()
+    # center_at() without argument only runs at B == 1 in the reference (its (1,3) default fails its own check)
+    sb = SB.from_xyz(xyz[:1].clone(), mask[:1]); sb.center_at(); out["center_origin_b1"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.center_at(centers); out["center_b"] = sb.get_xyz()
+    sb = SB.from_xyz(xyz.clone(), mask); sb.center_at(centers[0]); out["center_shared"] = sb.get_xyz()
+    xyz2, mask2 = synth(113, 2, 10, scale=5.0)
+    sb = SB.from_xyz(xyz2, mask2)
+    out["xyz2"] = xyz2
+    out["local_xyz"] = sb.get_local_xyz()
+    rot, tr = sb.backbone_orientations(), sb.backbone_translations()
+    for cb in (False, True):
+        sb3 = SB.from_backbone_orientations_translations(rot, tr, include_cb=cb)
+        out[f"bb_xyz_cb{int(cb)}"] = sb3.get_xyz()
+        out[f"bb_mask_cb{int(cb)}"] = sb3.get_atom_mask()
+    out["ideal3"] = geom.ideal_backbone_coordinates(size=(), include_cb=False)
+    out["ideal4"] = geom.ideal_backbone_coordinates(size=(), include_cb=True)
+    save("g11_rigid_ops", **out)
+
     # G9 free-function known answers, evaluated by the reference ---------------------------
     a = torch.tensor([[1.0, 0.0, 0.0]])
     b = torch.tensor([[0.0, 0.0, 0.0]])
