@@ -122,6 +122,20 @@ def test_k1_store_policy_variants_agree(SB):
                         _lib.set_tuning("k1_rows_per_block", rows)
                         d, m = ops.pairwise_distance(xyz, mask)
                         assert torch.equal(d, base[0]) and torch.equal(m, base[1]), (var, jt, nt, rows)
+        # flat table-decoded kernel (variant 2), every workgroup size, full matrix and row shards
+        _lib.set_tuning("k1_variant", 2)
+        for bd in (256, 512, 1024):
+            _lib.set_tuning("k1_flat_bd", bd)
+            d = torch.full_like(base[0], float("nan"))
+            m = torch.zeros_like(base[1])
+            ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
+            assert torch.equal(d, base[0]) and torch.equal(m, base[1]), ("flat", bd)
+            cd, cm = ops.pairwise_distance(xyz, mask, row_begin=37, row_end=101, compact=True)
+            assert torch.equal(cd, base[0][:, 37:101]) and torch.equal(cm, base[1][:, 37:101]), ("flat shard", bd)
+            d2 = torch.full_like(base[0], float("nan"))
+            ops.pairwise_distance(xyz, mask, row_begin=37, row_end=101, out_dist=d2, want_mask=False)
+            assert torch.equal(d2[:, 37:101], base[0][:, 37:101]) and d2[:, :37].isnan().all() and d2[:, 101:].isnan().all()
+        _lib.set_tuning("k1_flat_bd", 256)
     finally:
         _lib.set_tuning("k1_store_nt", nt0)
         _lib.set_tuning("k1_rows_per_block", rows0)
@@ -156,6 +170,27 @@ def test_k1_headline_shape_properties(SB):
     buf = torch.full((4, N, N, 15, 15), float("nan"), device="cuda")
     ops.pairwise_distance(sb.xyz[:4], sb.atom_mask[:4], out_dist=buf, want_mask=False)
     assert not torch.isnan(buf).any()
+
+
+def test_k1_large_n_2048(SB):
+    """BASELINE config 4's residue count (N=2048): 64-bit addressing and the row-range path at scale.
+    One structure (4.7 GB); sampled blocks vs the oracle's formula, mask checksum, one row shard."""
+    from protstruc_amd import ops
+    N = 2048
+    xyz, mask = synth(4, 1, N)
+    xg, mg = xyz.cuda(), mask.cuda()
+    d, m = ops.pairwise_distance(xg, mg)
+    g = torch.Generator().manual_seed(2)
+    is_ = torch.cat([torch.randint(0, N, (200,), generator=g), torch.tensor([0, N - 1, N - 1, 0])])
+    js = torch.cat([torch.randint(0, N, (200,), generator=g), torch.tensor([0, N - 1, 0, N - 1])])
+    want = torch.norm(xyz[0, is_][:, :, None, :] - xyz[0, js][:, None, :, :], dim=-1)
+    assert_close(d[0, is_.cuda(), js.cuda()], want)
+    assert torch.equal(m[0, is_.cuda(), js.cuda()].cpu(), mask[0, is_][:, :, None] & mask[0, js][:, None, :])
+    cnt = int(mask.sum())
+    assert int(m.sum(dtype=torch.int64)) == cnt * cnt
+    # rank 5 of 8 (rows 1280..1536) written into a NaN-prefilled compact buffer equals the full result
+    cd, cm = ops.pairwise_distance(xg, mg, row_begin=1280, row_end=1536, compact=True)
+    assert torch.equal(cd, d[:, 1280:1536]) and torch.equal(cm, m[:, 1280:1536])
 
 
 # ----------------------------------------------------------------------------- K2

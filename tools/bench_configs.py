@@ -154,6 +154,38 @@ def std_roundtrip():
     sb3.standardize()
 us = graph_time(std_roundtrip, n=20)
 out["K6_standardize_B256_N384"] = {"graph_us": us, "GBps": B * N * 45 * 4 * 4 / us / 1e3}
+# ---- CPU oracle (the reference's op sequence) on this box's host cores, bounded samples ----
+from oracle import protstruc_oracle as O
+
+
+def cpu_time(fn, min_s=2.0):
+    fn()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn(); n += 1
+        if time.perf_counter() - t0 > min_s:
+            break
+    return (time.perf_counter() - t0) / n
+
+
+cpu = {"threads": torch.get_num_threads(), "logical_cpus": os.cpu_count()}
+x2, m2 = synth(0, 64, 256)
+ci = torch.zeros(64, 256); ci[:, 128:] = 1
+cpu["config2_K2_backbone_dihedrals_B64_N256_ms"] = cpu_time(lambda: O.backbone_dihedrals(x2, ci, m2.any(-1))) * 1e3
+x3, m3 = synth(1, 4, 512)   # 4 of the 128 structures of config 3
+t = cpu_time(lambda: O.pairwise_dihedrals(x3, [1, 4], [1, 4]))
+cpu["config3_K3_dihedral_pairs_per_s"] = 4 * 512 * 512 / t
+t = cpu_time(lambda: O.pairwise_planar_angles(x3, [1, 4], [4]))
+cpu["config3_K3_planar_pairs_per_s"] = 4 * 512 * 512 / t
+x5, m5 = synth(2, 256, 384)
+beta5 = torch.full((256,), 0.01)
+t = cpu_time(lambda: O.diffuse_xyz(x5, beta5, torch.randn_like(x5)))
+cpu["config5_diffuse_xyz_us"] = t * 1e6
+t = cpu_time(lambda: O.backbone_orientations(x5))
+cpu["config5_backbone_orientations_us"] = t * 1e6
+t = cpu_time(lambda: O.standardize(x5, m5))
+cpu["config5_standardize_us"] = t * 1e6
+out["cpu_oracle_on_this_host"] = cpu
 print(json.dumps(out, indent=1))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(out, open("gpurun_out/bench_configs.json", "w"), indent=1)
