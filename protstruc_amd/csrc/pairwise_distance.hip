@@ -42,7 +42,6 @@ struct K1Tuning {
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
-    int flat_bd = 256;        // workgroup size of the flat kernel (variant 2): 256, 512 or 1024
 };
 K1Tuning g_k1;
 
@@ -438,129 +437,6 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     }
 }
 
-// ---- flat kernel (experiment, k1_variant = 2): aligned 16 KB chunks of the output stream ----
-// The store microbenchmarks say bytes-per-workgroup is what limits the write rate (57.6 KB: 5.65 TB/s,
-// 16 KB: 6.06, 4 KB: 6.9), so this kernel cuts the (structure-wide, contiguous) output stream into
-// chunks of 4096 elements: 1024 float4 slots of the distance plane (16 KB) and 256 16-byte slots of the
-// mask plane (4 KB), both aligned, every lane storing 16 bytes.  A chunk covers ~18.2 residue pairs that
-// may wrap from row i to row i+1, so the workgroup stages coordinates PER PAIR SLOT (xi and xj of up to 21
-// pairs).  The (pair, a, c) decode of a slot depends only on its phase r = element % 225, so it comes from
-// a 225-entry LDS table of byte offsets built once per workgroup.
-constexpr int FLAT_SLOTS = 1024;          // float4 slots per chunk
-constexpr int FLAT_ELEMS = 4 * FLAT_SLOTS;
-constexpr int FLAT_PAIRS = 21;            // pair slots staged: (224 + 4095) / 225 = 19 -> slots 0..19, +1 for the mask window
-
-template <int BD, bool NT>
-__global__ __launch_bounds__(BD) void k1_pairdist_a15_flat(const float* __restrict__ xyz,
-                                                            const uint8_t* __restrict__ amask,
-                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
-                                                            unsigned N, unsigned row_begin, unsigned nrows,
-                                                            unsigned out_rows, unsigned out_row_origin) {
-    __shared__ __attribute__((aligned(16))) float4 sxj[FLAT_PAIRS * RS];
-    __shared__ __attribute__((aligned(16))) float4 sxi[FLAT_PAIRS * RS];
-    __shared__ __attribute__((aligned(16))) uint4 tab[AA15];
-    __shared__ uint32_t smj[FLAT_PAIRS + 1], smi[FLAT_PAIRS + 1];
-
-    const unsigned tid = threadIdx.x;
-    const unsigned b = blockIdx.y;
-    const unsigned long long seg_elems = (unsigned long long)nrows * N * AA15;
-    const unsigned long long E0 = (unsigned long long)blockIdx.x * FLAT_ELEMS;   // first element of the chunk
-    const unsigned long long p0 = E0 / AA15;                                      // first pair of the chunk
-    const unsigned q0 = (unsigned)(E0 - p0 * AA15);
-    const unsigned il0 = (unsigned)(p0 / N), j0 = (unsigned)(p0 - (unsigned long long)il0 * N);
-    const unsigned long long seg_pairs = (unsigned long long)nrows * N;
-
-    // ---- stage xi / xj per pair slot ----
-    for (unsigned f = tid; f < FLAT_PAIRS * 45u; f += BD) {
-        const unsigned ps = f / 45u, r45 = f - ps * 45u;
-        const unsigned atom = r45 / 3u, comp = r45 - atom * 3u;
-        const unsigned jj = j0 + ps;
-        const unsigned k = (jj >= N) + (jj >= 2u * N);
-        const unsigned j = jj - k * N, il = il0 + k;
-        float vj = 0.f, vi = 0.f;
-        if (p0 + ps < seg_pairs) {
-            vj = xyz[((size_t)b * N + j) * 45u + r45];
-            vi = xyz[((size_t)b * N + row_begin + il) * 45u + r45];
-        }
-        reinterpret_cast<float*>(sxj)[(ps * RS + atom) * 4 + comp] = vj;
-        reinterpret_cast<float*>(sxi)[(ps * RS + atom) * 4 + comp] = vi;
-    }
-    if (tid < 2u * (FLAT_PAIRS + 1)) {
-        const bool is_j = tid <= FLAT_PAIRS;
-        const unsigned ps = is_j ? tid : tid - (FLAT_PAIRS + 1);
-        const unsigned jj = j0 + ps;
-        const unsigned k = (jj >= N) + (jj >= 2u * N);
-        uint32_t bits = 0;
-        if (ps < FLAT_PAIRS && p0 + ps < seg_pairs) {
-            if (amask) {
-                const unsigned res = is_j ? (jj - k * N) : (row_begin + il0 + k);
-                const uint8_t* m = amask + ((size_t)b * N + res) * A15;
-#pragma unroll
-                for (int c = 0; c < A15; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
-            } else {
-                bits = 0x7FFFu;
-            }
-        }
-        (is_j ? smj : smi)[ps] = bits;
-    }
-    // ---- decode table: phase r -> LDS byte offsets of the four elements of a slot starting at phase r ----
-    for (unsigned r = tid; r < (unsigned)AA15; r += BD) {
-        uint32_t w[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned e = r + k, dps = e >= (unsigned)AA15;
-            const unsigned rr = e - dps * AA15, a = rr / A15, c = rr - a * A15;
-            const unsigned oj = (dps * RS + c) * 16u, oi = (dps * RS + a) * 16u;   // bytes, < 512
-            w[k] = oj | (oi << 16);
-        }
-        tab[r] = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __syncthreads();
-
-    const size_t seg_base = ((size_t)b * out_rows + (row_begin - out_row_origin)) * N * AA15;  // elements
-    if (dist) {
-        const char* bj = reinterpret_cast<const char*>(sxj);
-        const char* bi = reinterpret_cast<const char*>(sxi);
-#pragma unroll
-        for (int it = 0; it < FLAT_SLOTS / BD; ++it) {
-            const unsigned ls = it * BD + tid;
-            if (E0 + 4ull * ls < seg_elems) {
-                const unsigned le0 = q0 + 4u * ls;
-                const unsigned ps = le0 / AA15, r0 = le0 - ps * AA15;
-                const uint4 t = tab[r0];
-                const unsigned base = ps * (RS * 16u);
-                uint4 u;
-                u.x = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.x >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.x & 0xFFFFu)))));
-                u.y = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.y >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.y & 0xFFFFu)))));
-                u.z = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.z >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.z & 0xFFFFu)))));
-                u.w = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.w >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.w & 0xFFFFu)))));
-                store16<NT>(dist + seg_base + E0 + 4ull * ls, u);
-            }
-        }
-    }
-    if (dmask) {
-        for (unsigned m = tid; m < FLAT_ELEMS / 16; m += BD) {
-            if (E0 + 16ull * m < seg_elems) {
-                const unsigned le0 = q0 + 16u * m;
-                const unsigned ps = le0 / AA15, r = le0 - ps * AA15;
-                const unsigned a = r / A15, c = r - a * A15;
-                const bool wa = (a == A15 - 1);
-                const unsigned a1 = wa ? 0u : a + 1u, ps1 = wa ? ps + 1u : ps;
-                const uint32_t row0 = ((smi[ps] >> a) & 1u) ? smj[ps] : 0u;
-                const uint32_t row1 = ((smi[ps1] >> a1) & 1u) ? smj[ps1] : 0u;
-                const uint32_t win = (row0 | (row1 << 15)) >> c;
-                uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
-                                     spread4((win >> 12) & 15u));
-                store16<NT>(dmask + seg_base + E0 + 16ull * m, u);
-            }
-        }
-    }
-}
-
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
@@ -601,21 +477,6 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     const int rows = row_end - row_begin;
     dim3 grid((N + JT - 1) / JT, (rows + IR - 1) / IR, B);
     size_t lds = (size_t)(JT + IR) * A15 * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
-    if (g_k1.variant == 2 && N % 16 == 0 && N >= 16 && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0) &&
-        ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0)) {
-        const unsigned long long seg_elems = (unsigned long long)rows * N * AA15;
-        const unsigned long long chunks = (seg_elems + FLAT_ELEMS - 1) / FLAT_ELEMS;
-        if (chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        dim3 fgrid((unsigned)chunks, B);
-#define PS_K1_FLAT(BD_)                                                                                            \
-    hipLaunchKernelGGL((k1_pairdist_a15_flat<BD_, false>), fgrid, dim3(BD_), 0, s, xyz, amask, dist, dmask,        \
-                       (unsigned)N, (unsigned)row_begin, (unsigned)rows, (unsigned)out_rows, (unsigned)out_row_origin)
-        if (g_k1.flat_bd == 1024) PS_K1_FLAT(1024);
-        else if (g_k1.flat_bd == 512) PS_K1_FLAT(512);
-        else PS_K1_FLAT(256);
-#undef PS_K1_FLAT
-        return ps_check_launch();
-    }
     const bool da = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
     const bool ma = (N % 16 == 0) && ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0);
 #define PS_K1_LAUNCH(NT_, DA_, MA_)                                                                                  \
@@ -665,11 +526,6 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
-    if (!strcmp(key, "k1_flat_bd")) {
-        if (value != 256 && value != 512 && value != 1024) return (int)hipErrorInvalidValue;
-        g_k1.flat_bd = value;
-        return 0;
-    }
     if (!strcmp(key, "k1_lds_pad_kb")) {
         if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
         g_k1.lds_pad_kb = value;
@@ -700,7 +556,6 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
-    else if (!strcmp(key, "k1_flat_bd")) *value = g_k1.flat_bd;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
