@@ -221,6 +221,22 @@ int ps_center_of_mass_f32(const float* xyz, float* com, int B, int N, int A, int
 int ps_frames_to_backbone_f32(const float* rot, const float* trans, const float* ideal, int n_ideal,
                               float* xyz, int B, int N, int A, void* stream);
 
+/*
+ * Batched Kabsch fit -- replaces the per-structure loop of StructureBatch.align and
+ * geometry.kabsch (protstruc.py:880-918, geometry.py:442-480): R[b] (3x3), t[b] (3) minimising the RMSD of
+ * R a + t against b over the atoms with atom_mask != 0.  src/dst are (B, n_atoms, 3); dst_is_shared /
+ * mask_is_shared = 1 when one target / one mask serves every structure.  Apply with ps_rigid_f32.
+ */
+int ps_kabsch_f32(const float* src_xyz, const float* dst_xyz, const uint8_t* atom_mask, float* R, float* t,
+                  int B, int n_atoms, int dst_is_shared, int mask_is_shared, void* stream);
+
+/*
+ * Distance of one atom slot of every residue of ONE structure to its nearest query point -- the distance
+ * part of StructureBatch.get_topk_nearest_residue_mask (protstruc.py:844-849).  xyz (N,A,3), query (n_query,3).
+ */
+int ps_min_dist_to_points_f32(const float* xyz, const float* query, float* out, int N, int A, int atom,
+                              int n_query, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

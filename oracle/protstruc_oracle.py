@@ -347,3 +347,43 @@ def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, include_cb: bool 
     xyz = torch.cat([placed, torch.zeros(B, N, n_slots - n_atoms, 3)], dim=-2)
     mask = torch.cat([torch.ones(B, N, n_atoms), torch.zeros(B, N, n_slots - n_atoms)], dim=-1)
     return xyz, mask
+
+
+# --------------------------------------------------------------------------
+# N4  Kabsch alignment, nearest-residue mask   reference: geometry.py:442-480, protstruc.py:819-918
+# --------------------------------------------------------------------------
+def kabsch(a: torch.Tensor, b: torch.Tensor):
+    """Rotation R and translation t minimising |R a + t - b| for point sets (n,3) (SVD of the covariance,
+    reflection removed through the sign of det)."""
+    ca, cb = a.mean(dim=-2, keepdim=True), b.mean(dim=-2, keepdim=True)
+    h = torch.einsum("ki,kj->ij", a - ca, b - cb)
+    u, _, vt = torch.linalg.svd(h)
+    v, ut = vt.transpose(-2, -1), u.transpose(-2, -1)
+    d = torch.sign(torch.linalg.det(v @ ut))
+    diag = torch.eye(3, dtype=a.dtype)
+    diag[2, 2] = d
+    rot = v @ diag @ ut
+    return rot, cb.squeeze(-2) - rot @ ca.squeeze(-2)
+
+
+def align(xyz: torch.Tensor, target_xyz: torch.Tensor, atom_mask: torch.Tensor) -> torch.Tensor:
+    """Each structure superimposed on its target over the masked atoms: x' = R x + t."""
+    B = xyz.shape[0]
+    out = torch.empty_like(xyz)
+    for b in range(B):
+        m = atom_mask[b].reshape(-1).bool()
+        r, t = kabsch(xyz[b].reshape(-1, 3)[m], target_xyz[b].reshape(-1, 3)[m])
+        out[b] = torch.einsum("ij,naj->nai", r, xyz[b]) + t
+    return out
+
+
+def topk_nearest_residue_mask(xyz_one: torch.Tensor, residue_mask_one: torch.Tensor, query: torch.Tensor, k: int = 128,
+                              mask: torch.Tensor = None) -> torch.Tensor:
+    """(1,N) mask of the k valid residues whose CA is nearest to any query point."""
+    ca = xyz_one[:, CA_SLOT]
+    dist = torch.norm(ca[:, None] - query, dim=-1).min(dim=-1).values
+    m = residue_mask_one if mask is None else residue_mask_one & mask
+    dist[~m] = 1e9
+    k = min(k, int(m.sum()))
+    idx = dist.topk(k, largest=False).indices
+    return torch.zeros(xyz_one.shape[0], dtype=torch.bool).scatter(0, idx, True).unsqueeze(0)

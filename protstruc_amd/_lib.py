@@ -39,6 +39,8 @@ SIGNATURES = {
     "ps_rigid_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_center_of_mass_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_frames_to_backbone_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_kabsch_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_min_dist_to_points_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_standardize_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),
     "ps_affine_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_stream]),
 }

@@ -353,3 +353,37 @@ def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, ideal: torch.Tens
                                                    n_slots, _stream(rot))
     _lib.check(rc, "ps_frames_to_backbone_f32")
     return xyz
+
+
+def kabsch(src: torch.Tensor, dst: torch.Tensor, atom_mask: torch.Tensor):
+    """Per-structure optimal (R (B,3,3), t (B,3)) taking ``src`` (B,N,A,3) onto ``dst`` ((B|1),N,A,3) over masked atoms."""
+    src = _f32c(src, "source xyz")
+    dst = _f32c(dst.to(src.device), "target xyz")
+    B = src.shape[0]
+    n_atoms = src[0].numel() // 3
+    if dst[0].numel() // 3 != n_atoms or dst.shape[0] not in (1, B):
+        raise ValueError("source and target must have the same number of atoms per structure")
+    m = _u8c(atom_mask.to(src.device), "atom_mask").reshape(-1, n_atoms)
+    if m.shape[0] not in (1, B):
+        raise ValueError("atom_mask must have the batch size of the source (or 1)")
+    dev = src.device
+    with torch.cuda.device(dev):
+        R = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
+        t = torch.empty(B, 3, dtype=torch.float32, device=dev)
+        rc = _lib.load().ps_kabsch_f32(_ptr(src), _ptr(dst), _ptr(m), _ptr(R), _ptr(t), B, n_atoms,
+                                       int(dst.shape[0] == 1 and B > 1), int(m.shape[0] == 1 and B > 1), _stream(src))
+    _lib.check(rc, "ps_kabsch_f32")
+    return R, t
+
+
+def min_dist_to_points(xyz_one: torch.Tensor, query: torch.Tensor, atom: int = 1) -> torch.Tensor:
+    """(N,) distance from atom slot ``atom`` of each residue of one structure (N,A,3) to its nearest query point."""
+    xyz_one = _f32c(xyz_one, "xyz")
+    query = _f32c(query.to(xyz_one.device), "query_xyz").reshape(-1, 3)
+    N, A = xyz_one.shape[:2]
+    with torch.cuda.device(xyz_one.device):
+        out = torch.empty(N, dtype=torch.float32, device=xyz_one.device)
+        rc = _lib.load().ps_min_dist_to_points_f32(_ptr(xyz_one), _ptr(query), _ptr(out), N, A, int(atom),
+                                                   query.shape[0], _stream(xyz_one))
+    _lib.check(rc, "ps_min_dist_to_points_f32")
+    return out

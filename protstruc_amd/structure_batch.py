@@ -285,6 +285,49 @@ class StructureBatch:
         translation = center - self.center_of_mass()          # (B,3) by broadcasting
         ops.rigid(self.xyz, None, translation.contiguous(), inplace=True)
 
+    def align(self, target: "StructureBatch", atom_mask: torch.BoolTensor = None) -> torch.Tensor:
+        """Superimpose every structure on ``target`` (Kabsch, over the atoms present in both) and move the
+        coordinates (reference protstruc.py:880-918).  One batched launch instead of the reference's Python
+        loop + SVD per structure.  A single-structure target serves the whole batch (the reference's loop
+        stops after the first structure in that case and applies its rotation to all).  Returns the
+        rotations (B,3,3) (the reference documents that but returns None)."""
+        if target.get_batch_size() != 1 and self.batch_size != target.get_batch_size():
+            raise ValueError("Batch size of the two structures must be the same.")
+        if atom_mask is None:
+            atom_mask = self.atom_mask * target.get_atom_mask().to(self.device)
+        R, t = ops.kabsch(self.xyz, target.get_xyz(), atom_mask.bool())
+        self.xyz = ops.rigid(self.xyz, R, t)
+        return R
+
+    def get_topk_nearest_residue_mask(self, query_xyz: torch.FloatTensor, k: int = 128,
+                                      mask: torch.BoolTensor = None) -> torch.BoolTensor:
+        """(1, N) mask of the k residues whose CA is nearest to any query point (protstruc.py:819-862)."""
+        if self.batch_size > 1:
+            raise ValueError("get_topk_nearest_residue_mask method is not defined "
+                             "for a StructureBatch with batch size > 1.")
+        dist = ops.min_dist_to_points(self.xyz[0], query_xyz, ATOM.CA)
+        _mask = self.residue_mask[0]
+        if mask is not None:
+            _mask = _mask & mask.to(self.device)
+        dist[~_mask] = 1e9
+        k = min(k, int(_mask.sum()))
+        _, idx = dist.topk(k, largest=False)   # selection of k indices: plain tensor op on the device
+        ret = torch.zeros(self.n_residues, dtype=torch.bool, device=self.device).scatter(0, idx, True)
+        return ret.unsqueeze(0)
+
+    def residue_masked_select(self, mask: torch.BoolTensor) -> "StructureBatch":
+        """Single-structure batch restricted to the residues in ``mask`` (protstruc.py:920-956)."""
+        if self.batch_size > 1:
+            raise ValueError("residue_masked_select method is not defined "
+                             "for a StructureBatch with batch size > 1.")
+        if mask.shape != self.residue_mask.shape:
+            raise ValueError(f"Mask shape {mask.shape} does not match residue mask shape {self.residue_mask.shape}.")
+        if mask.dtype != torch.bool:
+            raise ValueError("Mask must be a boolean tensor.")
+        mask = mask.to(self.device)
+        return StructureBatch(self.xyz[mask].unsqueeze(0), self.atom_mask[mask].unsqueeze(0),
+                              self.chain_idx[mask].unsqueeze(0), self.chain_ids, self.seq, device=self.device)
+
     # ------------------------------------------------------------------ A9 standardize
     def standardize(self, atom_mask: torch.BoolTensor = None, residue_mask: torch.BoolTensor = None):
         """Per-structure, per-axis zero-mean / unit-std coordinates (protstruc.py:696-734)."""

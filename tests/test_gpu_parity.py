@@ -629,6 +629,45 @@ def test_rigid_body_ops_golden(SB):
     assert geom.ideal_backbone_coordinates((16, 30)).shape == (16, 30, 3, 3)
 
 
+def test_align_topk_select_golden(SB):
+    g = load_golden("g12_align_topk")
+    xyz, mask, tgt, tmask = g["xyz"], g["atom_mask"], g["target_xyz"], g["target_mask"]
+    T = 5e-5   # coordinates at ~10 A scale, rotation from an SVD: a few fp32 ulps
+    sb = SB.from_xyz(xyz.clone(), mask)
+    R = sb.align(SB.from_xyz(tgt, tmask))
+    assert_close(sb.get_xyz(), g["aligned_default_mask"], tol=T)
+    assert R.shape == (2, 3, 3)
+    eye = torch.eye(3, device=R.device).expand(2, 3, 3)
+    assert (R @ R.transpose(-1, -2) - eye).abs().max() < 1e-5 and torch.allclose(torch.linalg.det(R), torch.ones(2, device=R.device), atol=1e-5)
+    sb = SB.from_xyz(xyz.clone(), mask)
+    sb.align(SB.from_xyz(tgt, tmask), atom_mask=g["ca_sel"])
+    assert_close(sb.get_xyz(), g["aligned_ca_only"], tol=T)
+    from protstruc_amd import ops
+    full = torch.ones(1, 24, 15, dtype=torch.bool)
+    R1, t1 = ops.kabsch(xyz[:1].cuda(), tgt[:1].cuda(), full)
+    assert_close(R1[0], g["kabsch_R"], tol=5e-6)
+    assert_close(t1[0], g["kabsch_t"], tol=T)
+    # a single-structure target serves the whole batch; aligning a rotated copy onto the original recovers it
+    q = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(1)))[0]
+    q = q * torch.sign(torch.linalg.det(q))
+    moved = torch.einsum("ij,bnaj->bnai", q, xyz) + torch.tensor([3.0, -2.0, 7.0])
+    sb = SB.from_xyz(moved, mask)
+    sb.align(SB.from_xyz(xyz[:1], mask[:1]), atom_mask=torch.ones(1, 24, 15, dtype=torch.bool))
+    assert (sb.get_xyz()[0].cpu() - xyz[0]).abs().max() < 1e-4
+    with pytest.raises(ValueError, match="Batch size"):
+        SB.from_xyz(xyz, mask).align(SB.from_xyz(torch.cat([tgt, tgt[:1]]), torch.cat([tmask, tmask[:1]])))
+    one = SB.from_xyz(xyz[:1], mask[:1], chain_idx=torch.zeros(1, 24), chain_ids=[["A"]])
+    assert torch.equal(one.get_topk_nearest_residue_mask(g["query"], k=5).cpu(), g["topk5"])
+    assert torch.equal(one.get_topk_nearest_residue_mask(g["query"], k=8, mask=g["topk_user_mask"]).cpu(), g["topk_masked"])
+    assert torch.equal(one.get_topk_nearest_residue_mask(g["query"]).cpu(), g["topk_all"])
+    with pytest.raises(ValueError, match="batch size > 1"):
+        SB.from_xyz(xyz, mask).get_topk_nearest_residue_mask(g["query"])
+    sel = one.residue_masked_select(g["pick"])
+    assert torch.equal(sel.get_xyz().cpu(), g["picked_xyz"]) and torch.equal(sel.get_atom_mask().cpu(), g["picked_mask"])
+    with pytest.raises(ValueError, match="boolean"):
+        one.residue_masked_select(g["pick"].float())
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")

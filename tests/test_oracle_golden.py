@@ -187,3 +187,18 @@ def test_rigid_body_ops():
         x, m = O.frames_to_backbone(rot, tr, include_cb=bool(cb))
         close(x, g[f"bb_xyz_cb{cb}"], tol=5e-6)
         assert m.dtype == g[f"bb_mask_cb{cb}"].dtype and torch.equal(m, g[f"bb_mask_cb{cb}"])
+
+
+def test_align_topk_select():
+    g = load_golden("g12_align_topk")
+    xyz, mask, tgt, tmask = g["xyz"], g["atom_mask"], g["target_xyz"], g["target_mask"]
+    close(O.align(xyz, tgt, mask & tmask), g["aligned_default_mask"], tol=2e-5)
+    close(O.align(xyz, tgt, g["ca_sel"]), g["aligned_ca_only"], tol=2e-5)
+    r, t = O.kabsch(xyz[0].reshape(-1, 3), tgt[0].reshape(-1, 3))
+    close(r, g["kabsch_R"], tol=2e-6)
+    close(t, g["kabsch_t"], tol=2e-5)
+    rmask = mask[0].any(-1)
+    assert torch.equal(O.topk_nearest_residue_mask(xyz[0], rmask, g["query"], 5), g["topk5"])
+    assert torch.equal(O.topk_nearest_residue_mask(xyz[0], rmask, g["query"], 8, g["topk_user_mask"]), g["topk_masked"])
+    assert torch.equal(O.topk_nearest_residue_mask(xyz[0], rmask, g["query"]), g["topk_all"])
+    assert torch.equal(xyz[:1][g["pick"]].unsqueeze(0), g["picked_xyz"])
