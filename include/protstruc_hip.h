@@ -43,8 +43,7 @@ const char* ps_error_string(int code);
  * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
  * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
  * "k1_variant" (0 = pattern kernel on aligned shapes, 1 = slot-decode kernel), "k1_jt" (64/128),
- * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values),
- * "k1_variant" = 3 with "k1_wave_ks" (4/8/16) selects the wave form of K1 in ps_pairwise_distance_ws_f32.
+ * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values).
  * Not part of the drop-in surface; has no reference counterpart.
  */
 int ps_set_tuning(const char* key, int value);
@@ -72,23 +71,6 @@ int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask,
                              int row_begin, int row_end,
                              int out_rows, int out_row_origin,
                              void* stream);
-
-/*
- * K1 with a caller-owned scratch buffer (same semantics and arguments as
- * ps_pairwise_distance_f32).  The workspace (ps_pairwise_distance_workspace_bytes
- * bytes, 16-byte aligned) receives a padded image of xyz / atom_mask that lets the
- * "wave" form of K1 stage its tiles with one 16-byte load per atom; when the
- * workspace is NULL / too small, or the shape is not eligible, this is exactly
- * ps_pairwise_distance_f32.  The library still never allocates.
- */
-size_t ps_pairwise_distance_workspace_bytes(int B, int N, int A);
-int ps_pairwise_distance_ws_f32(const float* xyz, const uint8_t* atom_mask,
-                                float* dist, uint8_t* dist_mask,
-                                int B, int N, int A,
-                                int row_begin, int row_end,
-                                int out_rows, int out_row_origin,
-                                void* workspace, size_t workspace_bytes,
-                                void* stream);
 
 /*
  * K2 -- replaces StructureBatch.backbone_dihedrals together with

@@ -22,9 +22,6 @@ SIGNATURES = {
     "ps_get_tuning": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int)]),
     "ps_pairwise_distance_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_int, _c_int, _c_stream]),
-    "ps_pairwise_distance_workspace_bytes": (ctypes.c_size_t, [_c_int, _c_int, _c_int]),
-    "ps_pairwise_distance_ws_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_int, _c_int, _c_int, _c_int, _c_int,
-                                             _c_int, _c_int, ctypes.c_void_p, ctypes.c_size_t, _c_stream]),
     "ps_backbone_dihedrals_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_u8p, _c_u8p, _c_int, _c_int,
                                            _c_int, _c_stream]),
     "ps_pairwise_angles_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),

@@ -42,7 +42,6 @@ struct K1Tuning {
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
-    int wave_ks = 8;          // wave kernel (variant 3): float4 slots per lane -> 4 KB * wave_ks/4 per workgroup
 };
 K1Tuning g_k1;
 
@@ -438,148 +437,6 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     }
 }
 
-// ---- wave kernel (k1_variant = 3, needs a caller-owned workspace) ----
-// Store microbenchmarks: the write rate depends on bytes per workgroup (57.6 KB: 5.65 TB/s ... 4 KB: 6.9), and
-// single-wave workgroups with wave-private staging hold ~6.1 TB/s almost independently of their VALU load.
-// So: one 64-lane workgroup per aligned chunk of 256*KS elements of the (structure-contiguous) output stream:
-// 64*KS float4 slots of the distance plane and 16*KS 16-byte slots of the mask plane.  Staging is wave-private
-// (no cross-wave barrier) and cheap because it reads a pre-padded image of the inputs prepared by a tiny
-// pre-kernel into the workspace: xyz4[b][n][16] float4 (one 16-byte load per atom) and bits[b][n] (the 15 mask
-// bytes of a residue packed into a word).  Slot decode uses a 225-entry table of LDS byte offsets in constant
-// memory (the decode of a slot depends only on its phase = element index mod 225).
-struct alignas(16) K1Tab {
-    uint32_t w[AA15][4];
-};
-constexpr K1Tab make_k1_tab() {
-    K1Tab t{};
-    for (int r = 0; r < AA15; ++r)
-        for (int k = 0; k < 4; ++k) {
-            const int e = r + k, dps = e >= AA15 ? 1 : 0;
-            const int rr = e - dps * AA15, a = rr / A15, c = rr - a * A15;
-            const uint32_t oj = (uint32_t)((dps * RS + c) * 16), oi = (uint32_t)((dps * RS + a) * 16);  // bytes < 512
-            t.w[r][k] = oj | (oi << 16);
-        }
-    return t;
-}
-__device__ __constant__ const K1Tab k1_tab = make_k1_tab();
-
-// workspace layout: [0, B*N*256) xyz4 image, then B*N uint32 mask words
-__global__ __launch_bounds__(256) void k1_prepare_workspace(const float* __restrict__ xyz,
-                                                            const uint8_t* __restrict__ amask, float4* __restrict__ xyz4,
-                                                            uint32_t* __restrict__ bits, size_t n_res) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // one lane per (residue, slot)
-    if (i >= n_res * RS) return;
-    const size_t res = i / RS;
-    const unsigned a = (unsigned)(i - res * RS);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (a < (unsigned)A15) {
-        const float* p = xyz + (res * A15 + a) * 3;
-        v = make_float4(p[0], p[1], p[2], 0.f);
-    }
-    xyz4[i] = v;
-    if (a == 0) {
-        uint32_t w = 0x7FFFu;
-        if (amask) {
-            w = 0;
-            const uint8_t* m = amask + res * A15;
-#pragma unroll
-            for (int c = 0; c < A15; ++c) w |= (m[c] != 0 ? 1u : 0u) << c;
-        }
-        bits[res] = w;
-    }
-}
-
-template <int KS, bool NT>
-__global__ __launch_bounds__(64) void k1_pairdist_a15_wave(const float4* __restrict__ xyz4,
-                                                           const uint32_t* __restrict__ bits, float* __restrict__ dist,
-                                                           uint8_t* __restrict__ dmask, unsigned N, unsigned row_begin,
-                                                           unsigned nrows, unsigned out_rows, unsigned out_row_origin) {
-    constexpr int ELEMS = 256 * KS;
-    constexpr int NS = (224 + ELEMS - 1) / AA15 + 2;  // pair slots touched by a chunk (+1 for the mask window)
-    __shared__ __attribute__((aligned(16))) float4 sxj[NS * RS];
-    __shared__ __attribute__((aligned(16))) float4 sxi[NS * RS];
-    __shared__ uint32_t smj[NS], smi[NS];
-
-    const unsigned lane = threadIdx.x, b = blockIdx.y;
-    const unsigned long long seg_pairs = (unsigned long long)nrows * N, seg_elems = seg_pairs * AA15;
-    const unsigned long long E0 = (unsigned long long)blockIdx.x * ELEMS;
-    const unsigned long long p0 = E0 / AA15;
-    const unsigned q0 = (unsigned)(E0 - p0 * AA15);
-    const unsigned il0 = (unsigned)(p0 / N), j0 = (unsigned)(p0 - (unsigned long long)il0 * N);
-    const size_t res0 = (size_t)b * N;
-
-    // ---- wave-private staging: NS pair slots x 16 float4 for the column residue and the row residue ----
-#pragma unroll
-    for (int idx0 = 0; idx0 < NS * RS; idx0 += 64) {
-        const unsigned idx = idx0 + lane;
-        if (idx < (unsigned)(NS * RS)) {
-            const unsigned ps = idx / RS, atom = idx % RS;
-            const unsigned jj = j0 + ps;
-            const unsigned k = (jj >= N) + (jj >= 2u * N);
-            float4 vj = make_float4(0.f, 0.f, 0.f, 0.f), vi = vj;
-            if (p0 + ps < seg_pairs) {
-                vj = xyz4[(res0 + jj - k * N) * RS + atom];
-                vi = xyz4[(res0 + row_begin + il0 + k) * RS + atom];
-            }
-            sxj[idx] = vj;
-            sxi[idx] = vi;
-        }
-    }
-    if (lane < (unsigned)NS) {
-        const unsigned jj = j0 + lane;
-        const unsigned k = (jj >= N) + (jj >= 2u * N);
-        const bool valid = p0 + lane < seg_pairs;
-        smj[lane] = valid ? bits[res0 + jj - k * N] : 0u;
-        smi[lane] = valid ? bits[res0 + row_begin + il0 + k] : 0u;
-    }
-    __syncthreads();  // one wave: orders the LDS writes above against the reads below
-
-    const size_t seg_base = ((size_t)b * out_rows + (row_begin - out_row_origin)) * N * AA15;  // elements
-    if (dist) {
-        const char* bj = reinterpret_cast<const char*>(sxj);
-        const char* bi = reinterpret_cast<const char*>(sxi);
-#pragma unroll
-        for (int it = 0; it < KS; ++it) {
-            const unsigned ls = it * 64 + lane;
-            if (E0 + 4ull * ls < seg_elems) {
-                const unsigned le0 = q0 + 4u * ls;
-                const unsigned ps = le0 / AA15, r0 = le0 - ps * AA15;
-                const uint4 t = *reinterpret_cast<const uint4*>(k1_tab.w[r0]);
-                const unsigned base = ps * (RS * 16u);
-                uint4 u;
-                u.x = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.x >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.x & 0xFFFFu)))));
-                u.y = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.y >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.y & 0xFFFFu)))));
-                u.z = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.z >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.z & 0xFFFFu)))));
-                u.w = __float_as_uint(dist_pp(lds_atom(reinterpret_cast<const float4*>(bi + base + (t.w >> 16))),
-                                              lds_atom(reinterpret_cast<const float4*>(bj + base + (t.w & 0xFFFFu)))));
-                store16<NT>(dist + seg_base + E0 + 4ull * ls, u);
-            }
-        }
-    }
-    if (dmask) {
-#pragma unroll
-        for (int it = 0; it < (ELEMS / 16 + 63) / 64; ++it) {
-            const unsigned m = it * 64 + lane;
-            if (m < (unsigned)(ELEMS / 16) && E0 + 16ull * m < seg_elems) {
-                const unsigned le0 = q0 + 16u * m;
-                const unsigned ps = le0 / AA15, r = le0 - ps * AA15;
-                const unsigned a = r / A15, c = r - a * A15;
-                const bool wa = (a == A15 - 1);
-                const unsigned a1 = wa ? 0u : a + 1u, ps1 = wa ? ps + 1u : ps;
-                const uint32_t row0 = ((smi[ps] >> a) & 1u) ? smj[ps] : 0u;
-                const uint32_t row1 = ((smi[ps1] >> a1) & 1u) ? smj[ps1] : 0u;
-                const uint32_t win = (row0 | (row1 << 15)) >> c;
-                uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
-                                     spread4((win >> 12) & 15u));
-                store16<NT>(dmask + seg_base + E0 + 16ull * m, u);
-            }
-        }
-    }
-}
-
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
@@ -669,11 +526,6 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
-    if (!strcmp(key, "k1_wave_ks")) {
-        if (value != 4 && value != 8 && value != 16) return (int)hipErrorInvalidValue;
-        g_k1.wave_ks = value;
-        return 0;
-    }
     if (!strcmp(key, "k1_lds_pad_kb")) {
         if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
         g_k1.lds_pad_kb = value;
@@ -704,7 +556,6 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
-    else if (!strcmp(key, "k1_wave_ks")) *value = g_k1.wave_ks;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
@@ -733,47 +584,5 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(k1_pairdist_generic, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist, dist_mask, N, A,
                        row_begin, row_end, out_rows, out_row_origin);
-    return ps_check_launch();
-}
-
-extern "C" size_t ps_pairwise_distance_workspace_bytes(int B, int N, int A) {
-    if (B <= 0 || N <= 0 || A != A15) return 0;
-    return (size_t)B * N * RS * sizeof(float4) + (size_t)B * N * sizeof(uint32_t);
-}
-
-extern "C" int ps_pairwise_distance_ws_f32(const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask,
-                                           int B, int N, int A, int row_begin, int row_end, int out_rows,
-                                           int out_row_origin, void* workspace, size_t workspace_bytes, void* stream) {
-    const bool wave_ok = g_k1.variant == 3 && A == A15 && N % 16 == 0 && N >= 32 && workspace &&
-                         workspace_bytes >= ps_pairwise_distance_workspace_bytes(B, N, A) &&
-                         (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 &&
-                         (reinterpret_cast<uintptr_t>(dist) & 15) == 0 && (reinterpret_cast<uintptr_t>(dist_mask) & 15) == 0;
-    if (!wave_ok)
-        return ps_pairwise_distance_f32(xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows,
-                                        out_row_origin, stream);
-    if (!xyz || (!dist && !dist_mask) || B < 0 || B > 65535) return (int)hipErrorInvalidValue;
-    if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
-    if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
-    if (B == 0 || row_begin == row_end) return 0;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    float4* xyz4 = reinterpret_cast<float4*>(workspace);
-    uint32_t* bits = reinterpret_cast<uint32_t*>(xyz4 + (size_t)B * N * RS);
-    const size_t n_res = (size_t)B * N;
-    hipLaunchKernelGGL(k1_prepare_workspace, dim3((unsigned)((n_res * RS + 255) / 256)), dim3(256), 0, s, xyz, atom_mask,
-                       xyz4, bits, n_res);
-    const int rows = row_end - row_begin;
-    const unsigned long long seg_elems = (unsigned long long)rows * N * AA15;
-#define PS_K1_WAVE(KS_)                                                                                            \
-    do {                                                                                                           \
-        const unsigned long long chunks = (seg_elems + 256ull * KS_ - 1) / (256ull * KS_);                          \
-        if (chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;                                              \
-        hipLaunchKernelGGL((k1_pairdist_a15_wave<KS_, false>), dim3((unsigned)chunks, B), dim3(64), 0, s, xyz4, bits, \
-                           dist, dist_mask, (unsigned)N, (unsigned)row_begin, (unsigned)rows, (unsigned)out_rows,   \
-                           (unsigned)out_row_origin);                                                              \
-    } while (0)
-    if (g_k1.wave_ks == 4) PS_K1_WAVE(4);
-    else if (g_k1.wave_ks == 16) PS_K1_WAVE(16);
-    else PS_K1_WAVE(8);
-#undef PS_K1_WAVE
     return ps_check_launch();
 }

@@ -51,18 +51,6 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-_WORKSPACES = {}
-
-
-def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Caller-owned scratch for K1 (grown on demand, one per device; the library never allocates)."""
-    ws = _WORKSPACES.get(device)
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-        _WORKSPACES[device] = ws
-    return ws
-
-
 def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
                       row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
                       out_dist: Optional[torch.Tensor] = None, out_mask: Optional[torch.Tensor] = None,
@@ -92,13 +80,10 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
             dmask = out_mask if out_mask is not None else torch.empty(shape, dtype=torch.bool, device=xyz.device)
             if dmask.shape != shape or dmask.dtype != torch.bool or not dmask.is_contiguous():
                 raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
-        lib = _lib.load()
-        ws_bytes = lib.ps_pairwise_distance_workspace_bytes(B, N, A)
-        ws = _workspace(xyz.device, ws_bytes) if ws_bytes else None
-        rc = lib.ps_pairwise_distance_ws_f32(
+        rc = _lib.load().ps_pairwise_distance_f32(
             _ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin,
-            _ptr(ws), ws_bytes if ws is not None else 0, _stream(xyz))
-    _lib.check(rc, "ps_pairwise_distance_ws_f32")
+            _stream(xyz))
+    _lib.check(rc, "ps_pairwise_distance_f32")
     return dist, dmask
 
 

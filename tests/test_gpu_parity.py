@@ -122,22 +122,6 @@ def test_k1_store_policy_variants_agree(SB):
                         _lib.set_tuning("k1_rows_per_block", rows)
                         d, m = ops.pairwise_distance(xyz, mask)
                         assert torch.equal(d, base[0]) and torch.equal(m, base[1]), (var, jt, nt, rows)
-        # wave kernel (variant 3, workspace-backed), every chunk size, full matrix and row shards
-        _lib.set_tuning("k1_variant", 3)
-        for ks in (4, 8, 16):
-            _lib.set_tuning("k1_wave_ks", ks)
-            d = torch.full_like(base[0], float("nan"))
-            m = torch.zeros_like(base[1])
-            ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
-            assert torch.equal(d, base[0]) and torch.equal(m, base[1]), ("wave", ks)
-            cd, cm = ops.pairwise_distance(xyz, mask, row_begin=37, row_end=101, compact=True)
-            assert torch.equal(cd, base[0][:, 37:101]) and torch.equal(cm, base[1][:, 37:101]), ("wave shard", ks)
-            d2 = torch.full_like(base[0], float("nan"))
-            ops.pairwise_distance(xyz, mask, row_begin=37, row_end=101, out_dist=d2, want_mask=False)
-            assert torch.equal(d2[:, 37:101], base[0][:, 37:101]) and d2[:, :37].isnan().all() and d2[:, 101:].isnan().all()
-            nm_d, nm_m = ops.pairwise_distance(xyz, None)
-            assert torch.equal(nm_d, base[0]) and bool(nm_m.all())
-        _lib.set_tuning("k1_wave_ks", 8)
     finally:
         _lib.set_tuning("k1_store_nt", nt0)
         _lib.set_tuning("k1_rows_per_block", rows0)
