@@ -42,7 +42,7 @@ const char* ps_error_string(int code);
 /*
  * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
  * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
- * "k1_variant" (0 = pattern kernel on aligned shapes, 1 = slot-decode kernel), "k1_jt" (64/128),
+ * "k1_variant" (0 = pattern kernel on aligned shapes, 1 = slot-decode kernel), "k1_jt" (64/128, 0 = auto),
  * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values).
  * Not part of the drop-in surface; has no reference counterpart.
  */

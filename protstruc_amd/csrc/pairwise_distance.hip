@@ -38,7 +38,7 @@ struct K1Tuning {
     int store_nt = 0;
     int rows_per_block = 1;   // IR
     int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
-    int jt = 64;              // column residues per tile (64 or 128)
+    int jt = 0;               // column residues per tile: 64, 128, or 0 = auto (128 when N >= 256: ~1 % faster at N = 512)
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
@@ -541,7 +541,7 @@ int ps_k1_set_tuning(const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "k1_jt")) {
-        if (value != 64 && value != 128) return (int)hipErrorInvalidValue;
+        if (value != 0 && value != 64 && value != 128) return (int)hipErrorInvalidValue;
         g_k1.jt = value;
         return 0;
     }
@@ -572,7 +572,8 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     const int rows = row_end - row_begin;
     if (A == A15) {
         if ((rows + g_k1.rows_per_block - 1) / g_k1.rows_per_block > 65535) return (int)hipErrorInvalidValue;
-        if (g_k1.jt == 128)
+        const int jt = g_k1.jt ? g_k1.jt : (N >= 256 ? 128 : 64);
+        if (jt == 128)
             return launch_a15<128>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
                                    s);
         return launch_a15<64>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);

@@ -113,7 +113,7 @@ def test_k1_store_policy_variants_agree(SB):
     nt0, rows0, var0, jt0 = (_lib.get_tuning(k) for k in ("k1_store_nt", "k1_rows_per_block", "k1_variant", "k1_jt"))
     try:
         for var in (0, 1):          # pattern kernel / slot-decode kernel
-            for jt in (64, 128):
+            for jt in (0, 64, 128):
                 for nt in (0, 1):
                     for rows in (1, 3, 8, 16):
                         _lib.set_tuning("k1_variant", var)
