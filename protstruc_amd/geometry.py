@@ -95,3 +95,12 @@ def gram_schmidt(a, b, c):
     """Orthonormal basis of the plane through (c-b) and (a-b), basis vectors as columns (reference geometry.py:413-439)."""
     (a, b, c), ft = _prep([a, b, c])
     return _finish(ops.pointwise(2, a, b, c), ft)
+
+
+def kabsch(a, b):
+    """Rotation (3,3) and translation (3,) minimising the RMSD of ``R a + t`` against ``b`` for point sets
+    (n,3) (reference geometry.py:442-480); evaluated by the batched Kabsch kernel with a batch of one."""
+    (a, b), ft = _prep([a, b])
+    mask = torch.ones(1, a.shape[0], dtype=torch.bool, device=a.device)
+    R, t = ops.kabsch(a.reshape(1, -1, 1, 3).contiguous(), b.reshape(1, -1, 1, 3).contiguous(), mask)
+    return _finish(R[0], ft), _finish(t[0], ft)

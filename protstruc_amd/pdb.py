@@ -33,6 +33,8 @@ THREE_TO_ONE = {
     "TRP": "W", "TYR": "Y", "UNK": "X",
 }
 CANONICAL = frozenset(k for k in THREE_TO_ONE if k != "UNK")
+# one-letter code -> integer code, alphabetical by one-letter code, X last (reference general.py:126-133)
+ONE_TO_INDEX = {c: k for k, c in enumerate("ACDEFGHIKLMNPQRSTVWYX")}
 
 # side-chain heavy atoms in slot order 5.. (slots 0-4 are N CA C O CB, slot 14 is OXT); reference general.py:149-171
 _SIDE_CHAIN = {

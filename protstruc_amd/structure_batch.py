@@ -148,6 +148,18 @@ class StructureBatch:
         atom_mask[:, :, :n_atoms] = 1.0
         return cls(xyz, atom_mask, chain_idx, chain_ids, seq, residue_idx, **kwargs)
 
+    @classmethod
+    def from_pdb_id(cls, pdb_id, **kwargs) -> "StructureBatch":
+        """The reference downloads entries from RCSB through biotite (protstruc.py:195-261).  Network access and
+        biotite are outside this build's scope: download the files yourself and use :meth:`from_pdb`."""
+        raise NotImplementedError("from_pdb_id needs network access and biotite; fetch the PDB file(s) and call "
+                                  "StructureBatch.from_pdb(path) instead")
+
+    @classmethod
+    def from_dihedrals(cls, dihedrals, chain_idx=None, chain_ids=None, **kwargs):
+        """Unimplemented in the reference as well (`# TODO`, protstruc.py:321-339)."""
+        raise NotImplementedError("from_dihedrals is a TODO stub in the reference (protstruc.py:321-339)")
+
     # ------------------------------------------------------------------ getters (protstruc.py:341-433)
     def get_batch_size(self) -> int:
         return self.batch_size
@@ -177,6 +189,16 @@ class StructureBatch:
 
     def get_seq(self):
         return self.seq
+
+    def get_seq_idx(self) -> torch.LongTensor:
+        """(B,N) integer amino-acid codes of the chains' sequences, UNK (20) in the padding (protstruc.py:394-409)."""
+        from .pdb import ONE_TO_INDEX
+
+        seq_idx = torch.full((self.batch_size, self.n_residues), ONE_TO_INDEX["X"], dtype=torch.long)
+        for i, (seqdict, chain_ids) in enumerate(zip(self.seq, self.chain_ids)):
+            concat = "".join(seqdict[c] for c in chain_ids)
+            seq_idx[i, : len(concat)] = torch.tensor([ONE_TO_INDEX[r] for r in concat], dtype=torch.long)
+        return seq_idx.to(self.device)
 
     def get_total_lengths(self) -> torch.LongTensor:
         return self.residue_mask.cumsum(dim=1).argmax(dim=1) + 1
@@ -236,6 +258,15 @@ class StructureBatch:
             if not ATOM.is_valid(atom):
                 raise ValueError(f"Atom {atom} is not valid.")
         return [int(ATOM[a]) for a in atoms_i], [int(ATOM[a]) for a in atoms_j]
+
+    def _pairwise_xyz(self, atoms_i: List[str], atoms_j: List[str]) -> torch.FloatTensor:
+        """(B, N*N, n_i+n_j, 3) gather of the reference (protstruc.py:589-618), kept for API compatibility only:
+        the angle kernels never build it (it is 1.6 GB at B=128, N=512)."""
+        si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
+        n = self.n_residues
+        coords_i = self.xyz[:, :, si].repeat_interleave(n, dim=1)
+        coords_j = self.xyz[:, :, sj].repeat(1, n, 1, 1)
+        return torch.cat([coords_i, coords_j], dim=-2)
 
     def pairwise_dihedrals(self, atoms_i: List[str], atoms_j: List[str]) -> torch.FloatTensor:
         """Dihedral of the four points (atoms_i of residue i ++ atoms_j of residue j) for all (i,j) (protstruc.py:620-640)."""

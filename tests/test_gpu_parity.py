@@ -668,6 +668,41 @@ def test_align_topk_select_golden(SB):
         one.residue_masked_select(g["pick"].float())
 
 
+def test_input_flavours(SB):
+    """numpy / float64 / non-contiguous / integer-mask / already-on-GPU inputs all give the same answer."""
+    xyz, mask = synth(321, 2, 20)
+    base_d, base_m = SB.from_xyz(xyz, mask).pairwise_distance_matrix()
+    flavours = {
+        "numpy64": (xyz.double().numpy(), mask.numpy()),
+        "gpu": (xyz.cuda(), mask.cuda()),
+        "noncontig": (xyz.permute(0, 1, 3, 2).contiguous().permute(0, 1, 3, 2), mask),
+        "longmask": (xyz, mask.long()),
+        "floatmask": (xyz, mask.float()),
+    }
+    for name, (x, m) in flavours.items():
+        sb = SB.from_xyz(x, m)
+        d, dm = sb.pairwise_distance_matrix()
+        assert torch.equal(d, base_d), name
+        assert torch.equal(dm.bool(), base_m), name
+        if name == "longmask":
+            assert dm.dtype == torch.long
+        dih, _ = sb.backbone_dihedrals()
+        assert dih.dtype == torch.float32 and dih.is_cuda
+    # chain indices given as float64 numpy
+    ci = np.zeros((2, 20)); ci[:, 10:] = 1
+    sb = SB.from_xyz(xyz.numpy(), mask.numpy(), chain_idx=ci, chain_ids=[["A", "B"]] * 2)
+    assert int(sb.get_n_terminal_mask().sum()) == 4
+    # _pairwise_xyz keeps the reference's (B, N*N, n, 3) layout: row p <-> (i = p // N, j = p % N)
+    pw = SB.from_xyz(xyz, mask)._pairwise_xyz(["CA", "CB"], ["N"])
+    assert pw.shape == (2, 400, 3, 3)
+    assert torch.equal(pw[:, 3 * 20 + 7, 0].cpu(), xyz[:, 3, 1]) and torch.equal(pw[:, 3 * 20 + 7, 2].cpu(), xyz[:, 7, 0])
+    import protstruc_amd.geometry as geom
+    g = load_golden("g12_align_topk")
+    R, t = geom.kabsch(g["xyz"][0].reshape(-1, 3), g["target_xyz"][0].reshape(-1, 3))
+    assert_close(R, g["kabsch_R"], tol=5e-6)
+    assert_close(t, g["kabsch_t"], tol=5e-5)
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")

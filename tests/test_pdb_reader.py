@@ -76,3 +76,13 @@ def test_altloc_hetatm_and_models(tmp_path):
     xyz, mask = p.get_atom_xyz()
     assert xyz[0, 1, 0] == 1.0 and mask[0].sum() == 2 and mask[1, 0] and not mask[2].any()
     assert p.get_seq() == "GMXXAAS"
+
+
+def test_seq_idx_from_pdb():
+    paths = [os.path.join(G, n) for n in ("15c8_HL.pdb", "1ad0_DC.pdb")]
+    sb = StructureBatch.from_pdb(paths, device="cpu")
+    idx = sb.get_seq_idx()
+    assert idx.shape == (2, 434) and idx.dtype == torch.long
+    assert idx[0, 0] == 2                      # ASP -> D -> 2 (reference general.py:126-133)
+    assert (idx[0, 229:] == 20).all()          # padding is UNK
+    assert idx.max() <= 20 and idx.min() >= 0
