@@ -52,11 +52,28 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+def _try_build_in_tree():
+    """The .so is a git-ignored build artefact; if it did not travel with the tree, compile it in place
+    (hipcc is part of the ROCm image).  Never a fallback to another code path: if this fails, load() raises."""
+    from . import build
+
+    if os.path.abspath(LIB_PATH) != os.path.abspath(build.LIB_PATH) or os.environ.get("PROTSTRUC_AMD_NO_AUTOBUILD"):
+        return
+    if not os.path.exists(build.HIPCC):
+        return
+    try:
+        build.build(force=True, verbose=True)
+    except Exception as exc:  # noqa: BLE001 -- reported by the caller as "library missing"
+        print(f"[protstruc_amd] in-tree build failed: {exc}", flush=True)
+
+
 def load():
     """Load the shared library once and type every entry point."""
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH):
+        _try_build_in_tree()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m protstruc_amd.build` "
