@@ -128,6 +128,11 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, steps=3):
 
 
 def main():
+    # Anything written to fd 1 by native libraries (RCCL prints a version banner to stdout on init) must not
+    # precede the one JSON line: send stdout to stderr for the whole run and restore it only to emit the result.
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -153,7 +158,8 @@ def main():
     dev = torch.device("cuda", local_rank % n_dev)  # ranks share a GPU only in gloo rehearsals
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("PS_BENCH_FORCE_DIST"))  # rehearsal: run the collective code path with one rank
+    if world > 1 or force_dist:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -226,13 +232,15 @@ def main():
     def emit():
         if rank == 0 and not printed.is_set():
             printed.set()
+            sys.stdout.flush()
+            os.dup2(saved_stdout_fd, 1)
             print(json.dumps(result), flush=True)
 
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(xyz_cpu, mask_cpu)
         result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
 
-    if world > 1 and not args.no_rowshard:
+    if (world > 1 or force_dist) and not args.no_rowshard:
         # The aux section must never cost the main line: a watchdog prints it and exits if RCCL stalls.
         def watchdog():
             time.sleep(240)
