@@ -35,10 +35,16 @@ def build(force=False, verbose=True):
     if not force and not is_stale():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [HIPCC] + FLAGS + ["-o", LIB_PATH] + sources()
+    tmp = f"{LIB_PATH}.{os.getpid()}.tmp"  # build aside and rename: concurrent builders (one per rank) cannot corrupt the .so
+    cmd = [HIPCC] + FLAGS + ["-o", tmp] + sources()
     if verbose:
         print("[protstruc_amd.build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, LIB_PATH)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB_PATH
 
 
