@@ -279,6 +279,59 @@ def test_k3_vs_oracle_conditioning_gate(SB, ai, aj, npts):
     assert nan_mismatch <= 1e-5
 
 
+def test_k3_config3_shape(SB):
+    """BASELINE config 3 (B=128, N=512): full launch, four structures checked against the oracle and fp64."""
+    B, N = 128, 512
+    xyz, mask = synth(3, B, N)
+    sb = SB.from_xyz(xyz, mask)
+    pick = [0, 37, 64, 127]
+    for (ai, aj, si, sj, npts) in [(["CA", "CB"], ["CA", "CB"], [1, 4], [1, 4], 4), (["N", "CA", "CB"], ["CB"], [0, 1, 4], [4], 4),
+                                   (["CA", "CB"], ["CB"], [1, 4], [4], 3)]:
+        got = (sb.pairwise_dihedrals if npts == 4 else sb.pairwise_planar_angles)(ai, aj)
+        assert got.shape == (B, N, N)
+        g = got[pick].cpu()
+        ref = (O.pairwise_dihedrals if npts == 4 else O.pairwise_planar_angles)(xyz[pick], si, sj)
+        truth = _f64_angles(xyz[pick], si, sj, npts)
+        off = ~torch.eye(N, dtype=torch.bool).expand(len(pick), N, N)
+        ok = off & ~(ref.isnan() | g.isnan())
+        wrap = (lambda d: torch.minimum(d.abs(), (2 * np.pi - d.abs()).abs())) if npts == 4 else (lambda d: d.abs())
+        assert (wrap(g - ref)[ok] > 1e-5).float().mean().item() <= 1e-4
+        assert wrap(g.double() - truth)[ok].max().item() <= max(4 * wrap(ref.double() - truth)[ok].max().item(), 2e-5)
+        diag = torch.diagonal(g, dim1=1, dim2=2)
+        assert ((diag == 0) & ~torch.signbit(diag)).all() if npts == 4 else diag.isnan().all()
+    geo = sb.inter_residue_geometry()
+    assert torch.equal(geo["omega"].isnan(), sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]).isnan())
+    assert torch.equal(geo["omega"].nan_to_num(0), sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]).nan_to_num(0))
+
+
+def test_config5_shape_diffusion_loop(SB):
+    """BASELINE config 5 shape (B=256, N=384): standardize once, then a short loop three ways --
+    step-by-step, fused steps, and the LDS-resident trajectory kernel -- must agree bit for bit."""
+    B, N, T = 256, 384, 6
+    xyz, mask = synth(5, B, N, scale=8.0)
+    betas = torch.linspace(1e-4, 0.05, T)[:, None].expand(T, B).contiguous()
+    a = SB.from_xyz(xyz.clone(), mask).manual_seed(77)
+    b = SB.from_xyz(xyz.clone(), mask).manual_seed(77)
+    c = SB.from_xyz(xyz.clone(), mask).manual_seed(77)
+    for sb in (a, b, c):
+        sb.standardize()
+    out, mu, std = O.standardize(xyz[:8], mask[:8])
+    assert_close(a.mu[:8], mu, tol=3e-5)
+    assert_close(a.get_xyz()[:8], out, tol=3e-5)
+    ra = []
+    for t in range(T):
+        a.diffuse_xyz(betas[t]); ra.append(a.backbone_orientations())
+        rb, _ = b.diffuse_xyz_and_frames(betas[t])
+        assert torch.equal(ra[-1], rb)
+    rc, tc, _ = c.diffuse_trajectory(betas)
+    assert torch.equal(rc, torch.stack(ra)) and torch.equal(a.get_xyz(), b.get_xyz()) and torch.equal(a.get_xyz(), c.get_xyz())
+    assert_close(rc[-1][:8], O.backbone_orientations(c.get_xyz()[:8].cpu()), bad_frac=1e-3)
+    # after T small-beta steps the masked statistics are still ~ (0, 1): mean drifts by O(sqrt(beta/n)), var stays ~1
+    z = c.get_xyz()[:8].cpu(); w = mask[:8].unsqueeze(-1).float()
+    mean = (z * w).sum((1, 2)) / w.sum((1, 2))
+    assert mean.abs().max() < 0.05
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)
