@@ -54,8 +54,9 @@ __device__ __forceinline__ float dist3(f3 a, f3 b) {
     return sqrt_rn_pos((sx + sy) + sz);
 }
 
-// x.norm(dim=-1) (geometry.py:29-31); sqrtf is the correctly rounded one
-__device__ __forceinline__ float norm3(f3 a) { return sqrtf(dot3(a, a)); }
+// x.norm(dim=-1) (geometry.py:29-31); correctly rounded sqrt in half the instructions of the library routine
+// (identical result unless the squared norm is subnormal, i.e. |a| < 1e-19)
+__device__ __forceinline__ float norm3(f3 a) { return sqrt_rn_pos(dot3(a, a)); }
 
 // np.cross component order: u1*v2 - u2*v1, ... two products then one subtract
 __device__ __forceinline__ f3 cross3(f3 u, f3 v) {
