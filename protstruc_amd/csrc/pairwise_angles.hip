@@ -38,7 +38,25 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
 #pragma unroll
     for (int k = 0; k < NP; ++k) pj[k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
 
-    for (int i = i0; i < i1; ++i) {
+    int i = i0;
+    if constexpr (NP == 4) {
+        // two rows per trip in the two halves of float2 registers -> packed v_pk_* math (bit-identical per element)
+        for (; i + 1 < i1; i += 2) {
+            const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
+            const float* s1 = s0 + (size_t)A * 3;
+            f3v p[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                p[k] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(s0 + sel.atom[k] * 3), load3(s1 + sel.atom[k] * 3));
+            const f32x2 v = dihedral4v(p[0], p[1], p[2], p[3]);
+            if (live) {
+                float* o = out + ((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j;
+                o[0] = v.x;
+                o[N] = v.y;
+            }
+        }
+    }
+    for (; i < i1; ++i) {
         const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
         f3 p[NP];
 #pragma unroll
@@ -72,25 +90,49 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         const uint8_t* mj = amask + ((size_t)b * N + jc) * A;
         mj_ca = mj[1] != 0; mj_o = mj[3] != 0; mj_cb = mj[4] != 0;
     }
-    for (int i = i0; i < i1; ++i) {
+    auto row_scalars = [&](int i, f3& n_i, f3& ca_i, f3& cb_i, uint8_t& mi_n, uint8_t& mi_ca, uint8_t& mi_cb) {
         const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
-        const f3 n_i = load3(si), ca_i = load3(si + 3), cb_i = load3(si + 12);
-        uint8_t mi_n = 1, mi_ca = 1, mi_cb = 1;
+        n_i = load3(si); ca_i = load3(si + 3); cb_i = load3(si + 12);
+        mi_n = mi_ca = mi_cb = 1;
         if (amask) {
             const uint8_t* mi = amask + ((size_t)b * N + i) * A;
             mi_n = mi[0] != 0; mi_ca = mi[1] != 0; mi_cb = mi[4] != 0;
         }
-        if (!live) continue;
-        const size_t o = ((size_t)b * N + i) * N + j;
+    };
+    auto row_planes = [&](size_t o, f3 n_i, f3 ca_i, f3 cb_i, uint8_t mi_n, uint8_t mi_ca, uint8_t mi_cb) {
         d_ca[o] = dist3(ca_i, ca_j);
         d_cb[o] = dist3(cb_i, cb_j);
         d_no[o] = dist3(n_i, o_j);
         m_ca[o] = mi_ca & mj_ca;
         m_cb[o] = mi_cb & mj_cb;
         m_no[o] = mi_n & mj_o;
+        phi[o] = angle3(ca_i, cb_i, cb_j);
+    };
+    int i = i0;
+    for (; i + 1 < i1; i += 2) {  // two rows per trip: the two dihedrals run as packed float2 math
+        f3 n0, ca0, cb0, n1, ca1, cb1;
+        uint8_t a0, b0, c0, a1, b1, c1;
+        row_scalars(i, n0, ca0, cb0, a0, b0, c0);
+        row_scalars(i + 1, n1, ca1, cb1, a1, b1, c1);
+        if (!live) continue;
+        const size_t o = ((size_t)b * N + i) * N + j;
+        row_planes(o, n0, ca0, cb0, a0, b0, c0);
+        row_planes(o + N, n1, ca1, cb1, a1, b1, c1);
+        const f3v cav = mk3v(ca0, ca1), cbv = mk3v(cb0, cb1), nv = mk3v(n0, n1), cajv = mk3v(ca_j, ca_j), cbjv = mk3v(cb_j, cb_j);
+        const f32x2 om = dihedral4v(cav, cbv, cajv, cbjv);   // as coded at protstruc.py:811
+        const f32x2 th = dihedral4v(nv, cav, cbv, cbjv);
+        omega[o] = om.x; omega[o + N] = om.y;
+        theta[o] = th.x; theta[o + N] = th.y;
+    }
+    for (; i < i1; ++i) {
+        f3 n_i, ca_i, cb_i;
+        uint8_t mi_n, mi_ca, mi_cb;
+        row_scalars(i, n_i, ca_i, cb_i, mi_n, mi_ca, mi_cb);
+        if (!live) continue;
+        const size_t o = ((size_t)b * N + i) * N + j;
+        row_planes(o, n_i, ca_i, cb_i, mi_n, mi_ca, mi_cb);
         omega[o] = dihedral4(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
         theta[o] = dihedral4(n_i, ca_i, cb_i, cb_j);
-        phi[o] = angle3(ca_i, cb_i, cb_j);
     }
 }
 

@@ -110,6 +110,35 @@ __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
     return atan2_ps(y, x);
 }
 
+// ---- two problems per lane: the same arithmetic on float2, which gfx950 issues as packed v_pk_* instructions ----
+// (K3 is VALU-issue bound; element for element the operations and their order are those of the scalar code above,
+// so the results are bit-identical.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct f3v {
+    f32x2 x, y, z;
+};
+
+__device__ __forceinline__ f3v mk3v(f3 a, f3 b) { return f3v{f32x2{a.x, b.x}, f32x2{a.y, b.y}, f32x2{a.z, b.z}}; }
+__device__ __forceinline__ f3v sub3v(f3v a, f3v b) { return f3v{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f32x2 dot3v(f3v a, f3v b) {
+    const f32x2 px = a.x * b.x, py = a.y * b.y, pz = a.z * b.z;
+    return ((f32x2{0.0f, 0.0f} + px) + py) + pz;
+}
+__device__ __forceinline__ f3v cross3v(f3v u, f3v v) {
+    f3v r;
+    r.x = u.y * v.z - u.z * v.y;
+    r.y = u.z * v.x - u.x * v.z;
+    r.z = u.x * v.y - u.y * v.x;
+    return r;
+}
+__device__ __forceinline__ f32x2 dihedral4v(f3v a, f3v b, f3v c, f3v d) {
+    const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2 = sub3v(d, c);
+    const f3v n1 = cross3v(b0, b1), n2 = cross3v(b2, b1), m = cross3v(n1, n2);
+    const f32x2 x = dot3v(n1, n2), ym = dot3v(m, b1), nn = dot3v(b1, b1);
+    return f32x2{atan2_ps(ym.x * __builtin_amdgcn_rsqf(nn.x), x.x), atan2_ps(ym.y * __builtin_amdgcn_rsqf(nn.y), x.y)};
+}
+
 // geometry.angle (geometry.py:64-71): no clamp before acos
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     f3 ba = sub3(a, b);
