@@ -218,7 +218,9 @@ def main():
         "config": {"workload": "pairwise_distance_matrix B=64 N_res=512 N_atom=15 (dist fp32 + bool mask), per GPU",
                    "global_batch": B * world, "n_res": N_RES, "n_atom": N_ATOM,
                    "parallelism": "replicas-of-batch" if world > 1 else "single-gpu",
-                   "k1_tuning": {k: _lib.get_tuning(k) for k in ("k1_variant", "k1_jt", "k1_rows_per_block", "k1_store_nt")}},
+                   "k1_tuning": {k: _lib.get_tuning(k) for k in ("k1_variant", "k1_jt", "k1_rows_per_block", "k1_store_nt",
+                                                                 "k1_xcd_remap")},
+                   "k1_autotune": ops.k1_autotune_result(dev)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "k1_pairdist_a15_pat", "kernel_ms": kernel_ms_max,

@@ -41,6 +41,7 @@ struct K1Tuning {
     int jt = 0;               // column residues per tile: 64, 128, or 0 = auto (128 when N >= 256: ~1 % faster at N = 512)
     int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
+    int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
 };
 K1Tuning g_k1;
@@ -310,7 +311,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
                                                            const uint8_t* __restrict__ amask,
                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                            int N, int row_begin, int row_end, int out_rows,
-                                                           int out_row_origin, int IR) {
+                                                           int out_row_origin, int IR, int n_tiles, int n_ichunks,
+                                                           int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sxj = reinterpret_cast<float4*>(smem);
     float4* sxi = sxj + JT * RS;
@@ -318,10 +320,18 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     uint32_t* smi = smj + (JT + 4);
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int j0 = blockIdx.x * JT;
+    // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (ids equal mod 8 share an XCD and its L2), so with
+    // xcd_remap each XCD sweeps its own contiguous eighth of the output: neighbouring runs -- which share 128-byte
+    // lines where a run is not line-aligned -- then meet in ONE L2, and every L2 streams a sequential address range.
+    // Store-only microbenchmark: 5.58 -> 5.90-5.99 TB/s at this granule (profiles/r01_store_microbench_10*.log).
+    // Placement is only a speed matter: any map from workgroup id to run is correct.
+    unsigned w = blockIdx.x;
+    if (xcd_remap) w = (w & 7u) * (gridDim.x >> 3) + (w >> 3);   // host guarantees gridDim.x % 8 == 0 when set
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_ichunks);
+    const int j0 = (int)tile * JT;
     const int jn = min(JT, N - j0);  // multiple of 16
-    const int i0 = row_begin + blockIdx.y * IR;
+    const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
     const int in = min(IR, row_end - i0);
 
     {
@@ -485,9 +495,13 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     if (da && ma && g_k1.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
                                (size_t)g_k1.lds_pad_kb * 1024;
+        const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
+        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        const int remap = (g_k1.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
 #define PS_K1_PAT(NT_, M_, U_)                                                                                     \
-    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), grid, dim3(256), lds_pat, s, xyz, amask, dist, dmask, \
-                       N, row_begin, row_end, out_rows, out_row_origin, IR)
+    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), dim3((unsigned)n_wg), dim3(256), lds_pat, s, xyz,    \
+                       amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, (int)grid.x,       \
+                       (int)grid.y, remap)
         if (g_k1.math == 1) PS_K1_PAT(false, 1, false);
         else if (g_k1.math == 2 && g_k1.unroll) PS_K1_PAT(false, 2, true);
         else if (g_k1.math == 2) PS_K1_PAT(false, 2, false);
@@ -526,6 +540,10 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.variant = value;
         return 0;
     }
+    if (!strcmp(key, "k1_xcd_remap")) {
+        g_k1.xcd_remap = value ? 1 : 0;
+        return 0;
+    }
     if (!strcmp(key, "k1_lds_pad_kb")) {
         if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
         g_k1.lds_pad_kb = value;
@@ -556,6 +574,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
+    else if (!strcmp(key, "k1_xcd_remap")) *value = g_k1.xcd_remap;
     else return (int)hipErrorInvalidValue;
     return 0;
 }

@@ -9,6 +9,7 @@ CPU path in this package.
 from __future__ import annotations
 
 import ctypes
+import time
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -51,6 +52,60 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
+# ---- one-time, per-device choice of K1's rows-per-workgroup -------------------------------------------------
+# MI355X devices differ: with the XCD-contiguous workgroup map, 2-4 residue rows per workgroup run at ~6.25 TB/s
+# on some GPUs and at 4.9-5.4 TB/s on others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log).
+# The first large eligible call therefore times the candidates on the caller's own buffers (results are identical
+# for every setting) and keeps the fastest for this process.  Never runs during stream capture.
+_K1_TUNED = {}
+_K1_CANDIDATE_ROWS = (1, 2, 4)
+
+
+def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
+    import os
+
+    if device in _K1_TUNED or A != 15 or N % 16 != 0 or n_pairs < (1 << 22):
+        return
+    if os.environ.get("PROTSTRUC_AMD_NO_AUTOTUNE") or torch.cuda.is_current_stream_capturing():
+        return
+    lib = _lib.load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+    def launch(rows):
+        _lib.set_tuning("k1_rows_per_block", rows)
+        _lib.check(lib.ps_pairwise_distance_f32(*args, stream), "ps_pairwise_distance_f32 (autotune)")
+
+    # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
+    # then time the candidates in interleaved rounds and keep each one's minimum
+    t_end = time.perf_counter() + 0.12
+    while time.perf_counter() < t_end:
+        launch(1)
+        torch.cuda.current_stream(device).synchronize()
+    timings = {rows: float("inf") for rows in _K1_CANDIDATE_ROWS}
+    for _ in range(3):
+        for rows in _K1_CANDIDATE_ROWS:
+            launch(rows)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            launch(rows)
+            launch(rows)
+            e1.record()
+            e1.synchronize()
+            timings[rows] = min(timings[rows], e0.elapsed_time(e1) / 2)
+    best_rows, best_ms = 1, timings[1]
+    for rows in _K1_CANDIDATE_ROWS[1:]:
+        if timings[rows] < best_ms * 0.985:   # prefer fewer rows unless the gain is clear
+            best_rows, best_ms = rows, timings[rows]
+    _lib.set_tuning("k1_rows_per_block", best_rows)
+    _K1_TUNED[device] = {"rows_per_block": best_rows, "ms": timings}
+
+
+def k1_autotune_result(device=None):
+    """What the one-time K1 autotune chose on ``device`` (None if it has not run)."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    return _K1_TUNED.get(device)
+
+
 def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
                       row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
                       out_dist: Optional[torch.Tensor] = None, out_mask: Optional[torch.Tensor] = None,
@@ -80,9 +135,9 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
             dmask = out_mask if out_mask is not None else torch.empty(shape, dtype=torch.bool, device=xyz.device)
             if dmask.shape != shape or dmask.dtype != torch.bool or not dmask.is_contiguous():
                 raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
-        rc = _lib.load().ps_pairwise_distance_f32(
-            _ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin,
-            _stream(xyz))
+        args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
+        _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A)
+        rc = _lib.load().ps_pairwise_distance_f32(*args, _stream(xyz))
     _lib.check(rc, "ps_pairwise_distance_f32")
     return dist, dmask
 

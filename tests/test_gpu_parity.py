@@ -120,13 +120,46 @@ def test_k1_store_policy_variants_agree(SB):
                         _lib.set_tuning("k1_jt", jt)
                         _lib.set_tuning("k1_store_nt", nt)
                         _lib.set_tuning("k1_rows_per_block", rows)
-                        d, m = ops.pairwise_distance(xyz, mask)
-                        assert torch.equal(d, base[0]) and torch.equal(m, base[1]), (var, jt, nt, rows)
+                        for remap in (0, 1):
+                            _lib.set_tuning("k1_xcd_remap", remap)
+                            d = torch.full_like(base[0], float("nan"))
+                            m = torch.zeros_like(base[1])
+                            ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
+                            assert torch.equal(d, base[0]) and torch.equal(m, base[1]), (var, jt, nt, rows, remap)
     finally:
         _lib.set_tuning("k1_store_nt", nt0)
         _lib.set_tuning("k1_rows_per_block", rows0)
         _lib.set_tuning("k1_variant", var0)
         _lib.set_tuning("k1_jt", jt0)
+
+
+def test_k1_autotune_is_transparent(SB):
+    """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
+    from protstruc_amd import _lib, ops
+    xyz, mask = synth(12, 16, 512)   # 4.2 M pairs: large enough to trigger the autotune if it has not run yet
+    xg, mg = xyz.cuda(), mask.cuda()
+    ops._K1_TUNED.pop(xg.device, None)
+    rows0 = _lib.get_tuning("k1_rows_per_block")
+    try:
+        _lib.set_tuning("k1_rows_per_block", 1)
+        import os
+        os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"
+        d0, m0 = ops.pairwise_distance(xg, mg)
+        assert ops.k1_autotune_result(xg.device) is None
+        del os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"]
+        d1, m1 = ops.pairwise_distance(xg, mg)
+        res = ops.k1_autotune_result(xg.device)
+        assert res is not None and res["rows_per_block"] in (1, 2, 4) and set(res["ms"]) == {1, 2, 4}
+        assert _lib.get_tuning("k1_rows_per_block") == res["rows_per_block"]
+        assert torch.equal(d0, d1) and torch.equal(m0, m1)
+        g = torch.cuda.CUDAGraph()            # a captured call never autotunes and still works
+        ops._K1_TUNED.pop(xg.device, None)
+        with torch.cuda.graph(g):
+            d2, m2 = ops.pairwise_distance(xg, mg)
+        g.replay(); torch.cuda.synchronize()
+        assert ops.k1_autotune_result(xg.device) is None and torch.equal(d2, d0)
+    finally:
+        _lib.set_tuning("k1_rows_per_block", rows0)
 
 
 def test_k1_headline_shape_properties(SB):

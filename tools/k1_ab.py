@@ -3,6 +3,7 @@
 usage: k1_ab.py "variant=0,jt=64,rows_per_block=1,unroll=0" "variant=0,jt=64,rows_per_block=1,unroll=1" ..."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"   # this harness sets every knob itself
 import torch
 from protstruc_amd import _lib, ops
 B, N, A = 64, 512, 15
@@ -11,7 +12,7 @@ xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9); mask[:, :, :3] = True; mask = mask.cuda()
 dist = torch.empty(B, N, N, A, A, device="cuda")
 dmask = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0)
+DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0, xcd_remap=1)
 cfgs = []
 for arg in sys.argv[1:]:
     c = dict(DEFAULT)

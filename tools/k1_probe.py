@@ -4,6 +4,8 @@ import json
 import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os
+os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
 import torch
 from protstruc_amd import _lib, ops
 

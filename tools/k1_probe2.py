@@ -2,6 +2,8 @@
 """K1 experiments: where is the time going?  math modes x tile x rows, interleaved rounds."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os
+os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
 import torch
 from protstruc_amd import _lib, ops
 B, N, A = 64, 512, 15
