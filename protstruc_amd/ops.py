@@ -100,6 +100,14 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
     _K1_TUNED[device] = {"rows_per_block": best_rows, "ms": timings}
 
 
+def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,
+                               out_mask: torch.Tensor):
+    """Run the one-time per-device K1 autotune now (library initialisation), on the given buffers."""
+    pairwise_distance(xyz, atom_mask, out_dist=out_dist, out_mask=out_mask)
+    torch.cuda.current_stream(xyz.device).synchronize()
+    return k1_autotune_result(xyz.device)
+
+
 def k1_autotune_result(device=None):
     """What the one-time K1 autotune chose on ``device`` (None if it has not run)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
