@@ -21,6 +21,10 @@
 //     the mask) shift the slot grid so stores stay aligned and the ragged head
 //     and tail are written element-wise.
 //
+// Three A = 15 kernels share that scheme.  Shapes with N % 16 == 0 take the "pattern" kernel (fixed per-lane
+// decode, row atoms in registers); any other N >= 16 takes the "flat pattern" kernel (the same fixed decode laid
+// over the flat pair axis, so rows need no alignment at all); the slot-decode kernel described above remains for
+// N < 16, unaligned planes and as the bit-identity cross-check in the tests.
 // Any A other than 15 takes the generic element-per-lane kernel at the bottom.
 #include "ps_common.hpp"
 #include <string.h>
@@ -43,6 +47,8 @@ struct K1Tuning {
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
+    int flat = 1;             // flat pattern kernel: 0 never, 1 for lengths the pattern kernel cannot take (N % 16 != 0), 2 always
+    int flat_cpw = 0;         // flat kernel: consecutive 128-pair chunks per workgroup; 0 = auto (4 on large launches, else 1)
 };
 K1Tuning g_k1;
 
@@ -447,6 +453,225 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     }
 }
 
+// ---- flat pattern kernel (any N >= 16, 16-byte aligned planes) ----
+// The same fixed-lane pattern, laid over the FLAT pair axis P = (b*out_rows + il)*N + j instead of over one row:
+// four consecutive pairs are 225 float4 slots and sixteen consecutive pairs are 225 16-byte mask slots whatever
+// N is, because a pair is 225 elements and the planes start 16-byte aligned.  A workgroup takes chunks of FL = 128
+// consecutive pairs.  Its LDS image is indexed by PAIR POSITION: slot p holds the column residue of pair P0 + p
+// (j wraps at N and moves on to the next structure), so the inner loop is the pattern kernel's.  What changes:
+//   * a chunk touches up to FR rows; the row atoms a lane needs are re-read from LDS at each row change, and the
+//     (at most one per row) 4-pair group that straddles two rows takes an element-wise path;
+//   * the mask uses a per-pair-position word (column bits | row bits << 16), so its 16-pair groups need no row
+//     bookkeeping at all;
+//   * [pbeg, pend) need not be 16-pair aligned (odd N; one structure of a row-sharded launch): partially active
+//     groups take the element-wise path and inactive pairs are never written.
+constexpr int FL = 128;  // pairs per chunk
+constexpr int FR = 16;   // row residues staged per chunk (N >= 16 -> a chunk touches at most 9 rows)
+
+// floor(x / d) for x, d < 2^23 with rcp = 1.0f / d
+__device__ __forceinline__ unsigned udiv_rcp(unsigned x, unsigned d, float rcp) {
+    unsigned q = (unsigned)((float)x * rcp);
+    const int r = (int)x - (int)(q * d);
+    if (r < 0) --q;
+    else if (r >= (int)d) ++q;
+    return q;
+}
+
+template <bool NT, bool HASMASK>
+__global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __restrict__ xyz,
+                                                            const uint8_t* __restrict__ amask,
+                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                            int B, int N, int out_rows, int out_row_origin,
+                                                            unsigned pbeg, unsigned pend, unsigned n_chunks,
+                                                            int cpw, int xcd_remap, double rcpN_d, double rcpR_d) {
+    __shared__ __attribute__((aligned(16))) float4 sxj[FL * RS];
+    __shared__ __attribute__((aligned(16))) float4 sxi[FR * RS];
+    __shared__ uint32_t smj[FL], smi[FR], smc[FL];
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) {  // XCD x (= w % 8) sweeps a contiguous share of the chunks; see the pattern kernel
+        const unsigned n = gridDim.x, x = w & 7u;
+        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
+    }
+    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
+    const unsigned c_first = pbeg >> 7;
+    const int pl = tid >> 4, c16 = tid & 15;  // staging: 16 lanes per residue
+
+    for (int cc = 0; cc < cpw; ++cc) {
+        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
+        if (chunk >= n_chunks) break;  // uniform
+        if (cc) __syncthreads();       // the previous chunk's LDS image is still being read
+        const unsigned P0 = (c_first + chunk) << 7;
+        const int lo = pbeg > P0 ? (int)(pbeg - P0) : 0;
+        const int hi = pend - P0 < (unsigned)FL ? (int)(pend - P0) : FL;
+        // row / structure of the chunk's first pair: exact via fp64 (P0 < 2^32) with a +-1 fix-up
+        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
+        if (R0 * (unsigned long long)N > P0) --R0;
+        else if ((R0 + 1ull) * N <= P0) ++R0;
+        const int j_start = (int)(P0 - R0 * (unsigned)N);
+        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
+        if (b0 * (unsigned long long)out_rows > R0) --b0;
+        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
+        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
+        const int nr = (j_start + FL - 1) / N + 1;  // rows the chunk touches
+
+        // ---- stage: column residue of every pair position, the touched row residues, their mask bits ----
+        // All global loads are issued before the first LDS write so the chunk pays one memory round trip, and the
+        // (row, column, structure) of a lane's pair position is walked from pass to pass (p grows by 16 <= N, so at
+        // most one row change per pass) instead of divided out again.
+        float vx[FL / 16 + 1], vy[FL / 16 + 1], vz[FL / 16 + 1];
+        unsigned vm[FL / 16 + 1];  // raw mask bytes: compared only after every load has been issued
+        bool va[FL / 16 + 1];
+        {
+            unsigned rl = udiv_rcp((unsigned)(j_start + pl), (unsigned)N, rcpN);
+            unsigned j = (unsigned)(j_start + pl) - rl * (unsigned)N;
+            const unsigned db = udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
+            unsigned il = il0 + rl - db * (unsigned)out_rows;
+            unsigned res0 = (b0 + db) * (unsigned)N;  // first residue of the pair's structure
+#pragma unroll
+            for (int pass = 0; pass < FL / 16; ++pass) {
+                const int p = pass * 16 + pl;
+                va[pass] = (p >= lo) && (p < hi) && (c16 < A15);
+                const unsigned src = va[pass] ? (res0 + j) * A15 + c16 : 0u;  // inactive lanes re-read atom 0
+                vx[pass] = xyz[src * 3u + 0];
+                vy[pass] = xyz[src * 3u + 1];
+                vz[pass] = xyz[src * 3u + 2];
+                vm[pass] = HASMASK ? (unsigned)amask[src] : 1u;
+                j += 16;
+                if (j >= (unsigned)N) {
+                    j -= (unsigned)N;
+                    if (++il == (unsigned)out_rows) {
+                        il = 0;
+                        res0 += (unsigned)N;
+                    }
+                }
+            }
+        }
+        {
+            const unsigned ilr = il0 + (unsigned)pl;
+            const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
+            const unsigned bb = b0 + db;
+            const unsigned i = ilr - db * (unsigned)out_rows + (unsigned)out_row_origin;
+            constexpr int L = FL / 16;
+            va[L] = (pl < nr) && (bb < (unsigned)B) && (c16 < A15);
+            const unsigned src = va[L] ? (bb * (unsigned)N + i) * A15 + c16 : 0u;
+            vx[L] = xyz[src * 3u + 0];
+            vy[L] = xyz[src * 3u + 1];
+            vz[L] = xyz[src * 3u + 2];
+            vm[L] = HASMASK ? (unsigned)amask[src] : 1u;
+        }
+#pragma unroll
+        for (int pass = 0; pass < FL / 16; ++pass) {
+            const int p = pass * 16 + pl;
+            sxj[p * RS + c16] = va[pass] ? make_float4(vx[pass], vy[pass], vz[pass], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned long long bal = __ballot(va[pass] && vm[pass] != 0u);
+            if (c16 == 0) smj[p] = (uint32_t)(bal >> (16 * (pl & 3))) & 0x7FFFu;
+        }
+        {
+            constexpr int L = FL / 16;
+            sxi[pl * RS + c16] = va[L] ? make_float4(vx[L], vy[L], vz[L], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned long long bal = __ballot(va[L] && vm[L] != 0u);
+            if (c16 == 0) smi[pl] = (uint32_t)(bal >> (16 * (pl & 3))) & 0x7FFFu;
+        }
+        __syncthreads();
+        if (dmask && tid < FL) {
+            const unsigned rl = udiv_rcp((unsigned)(j_start + tid), (unsigned)N, rcpN);
+            smc[tid] = (tid >= lo && tid < hi) ? (smj[tid] | (smi[rl] << 16)) : 0u;
+        }
+        __syncthreads();
+        if (tid >= AA15) continue;  // idle in the sweep; rejoins at the next chunk's barrier
+
+        if (dist) {
+            unsigned offj[4], ai[4], jo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned e = 4u * tid + k;  // element inside a 4-pair group
+                jo[k] = e / AA15;
+                const unsigned r = e - jo[k] * AA15;
+                ai[k] = r / A15;
+                offj[k] = jo[k] * RS + (r - ai[k] * A15);
+            }
+            float* o = dist + (size_t)P0 * AA15 + 4u * tid;
+            int rl = 0;                // row of pair 4g
+            int nb = N - j_start;      // pair position where row rl + 1 starts
+            int g = 0;
+            while (g < FL / 4) {
+                const int p = 4 * g;
+                if (p >= hi) break;
+                while (nb <= p) {
+                    ++rl;
+                    nb += N;
+                }
+                const int pe = min(nb, hi);
+                const int nfast = (p >= lo) ? (pe - p) >> 2 : 0;
+                if (nfast > 0) {  // whole groups inside one row and inside the active range
+                    float4 pi[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pi[k] = sxi[rl * RS + ai[k]];
+#pragma unroll 4
+                    for (int q = 0; q < nfast; ++q) {
+                        const float4* x = sxj + (g + q) * (4 * RS);
+                        const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
+                        const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
+                        uint4 u;
+                        u.x = __float_as_uint(dist_pp(pi[0], q0));
+                        u.y = __float_as_uint(dist_pp(pi[1], q1));
+                        u.z = __float_as_uint(dist_pp(pi[2], q2));
+                        u.w = __float_as_uint(dist_pp(pi[3], q3));
+                        store16<NT>(o + (size_t)(g + q) * (4 * AA15), u);
+                    }
+                    g += nfast;
+                    continue;
+                }
+                if (p + 4 > lo) {  // straddles a row change or the edge of the active range: element-wise
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int pp = p + (int)jo[k];
+                        if (pp >= lo && pp < hi) {
+                            const int rk = rl + (pp >= nb ? 1 : 0);  // N >= 16: at most one row change per group
+                            const float4 xi = sxi[rk * RS + ai[k]];
+                            const float4 xq = sxj[g * (4 * RS) + offj[k]];
+                            o[(size_t)g * (4 * AA15) + k] = dist_pp(xi, xq);
+                        }
+                    }
+                }
+                ++g;
+            }
+        }
+
+        if (dmask) {
+            const unsigned e0 = 16u * tid;  // byte inside a 16-pair group
+            const unsigned jo = e0 / AA15, r = e0 - jo * AA15;
+            const unsigned a = r / A15, c = r - a * A15;
+            const bool wa = (a == A15 - 1);
+            const unsigned a1 = wa ? 0u : a + 1u;
+            const unsigned jo1 = wa ? jo + 1u : jo;
+            uint8_t* o = dmask + (size_t)P0 * AA15 + 16u * tid;
+#pragma unroll
+            for (int g = 0; g < FL / 16; ++g) {
+                const int pg = 16 * g;
+                if (pg < hi && pg + 16 > lo) {
+                    const uint32_t w0 = smc[pg + jo], w1 = smc[pg + jo1];
+                    const uint32_t row0 = ((w0 >> (16u + a)) & 1u) ? (w0 & 0x7FFFu) : 0u;
+                    const uint32_t row1 = ((w1 >> (16u + a1)) & 1u) ? (w1 & 0x7FFFu) : 0u;
+                    const uint32_t win = ((row0 | (row1 << 15)) >> c) & 0xFFFFu;
+                    if (pg >= lo && pg + 16 <= hi) {
+                        uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                             spread4((win >> 12) & 15u));
+                        store16<NT>(o + (size_t)g * (16 * AA15), u);
+                    } else {
+                        for (unsigned t = 0; t < 16u; ++t) {
+                            const int pp = pg + (int)((c + t < (unsigned)A15) ? jo : jo1);
+                            if (pp >= lo && pp < hi) o[(size_t)g * (16 * AA15) + t] = (uint8_t)((win >> t) & 1u);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
@@ -521,6 +746,39 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     return ps_check_launch();
 }
 
+// Flat pattern kernel over the output pair range [pbeg, pend) (pair index P = (b*out_rows + il)*N + j).
+bool flat_eligible(const float* dist, const uint8_t* dmask, int B, int N, int out_rows) {
+    if (g_k1.variant != 0 || g_k1.flat == 0) return false;
+    if (N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
+    if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;  // pair indices stay 32-bit
+    if ((unsigned long long)B * N * (A15 * 3) >= 0x80000000ull) return false;  // and so do coordinate indices
+    if ((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15)) return false;
+    return g_k1.flat == 2 || N % 16 != 0;
+}
+
+int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int out_rows,
+                    int out_row_origin, unsigned pbeg, unsigned pend, hipStream_t s) {
+    if (pbeg >= pend) return 0;
+    const unsigned n_chunks = ((pend + (FL - 1)) >> 7) - (pbeg >> 7);
+    // four chunks per workgroup are 1-2 % faster once there are plenty of workgroups (profiles/r01_k1_n_sweep.log)
+    const unsigned cpw = g_k1.flat_cpw ? (unsigned)g_k1.flat_cpw : (n_chunks >= 16384u ? 4u : 1u);
+    const unsigned n_wg = (n_chunks + cpw - 1) / cpw;
+    const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
+#define PS_K1_FLAT(NT_, HM_)                                                                                       \
+    hipLaunchKernelGGL((k1_pairdist_a15_flat<NT_, HM_>), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N, \
+                       out_rows, out_row_origin, pbeg, pend, n_chunks, (int)cpw, remap, rn, rr)
+    if (g_k1.store_nt) {
+        if (amask) PS_K1_FLAT(true, true);
+        else PS_K1_FLAT(true, false);
+    } else {
+        if (amask) PS_K1_FLAT(false, true);
+        else PS_K1_FLAT(false, false);
+    }
+#undef PS_K1_FLAT
+    return ps_check_launch();
+}
+
 }  // namespace
 
 extern "C" int ps_k1_set_tuning(const char* key, int value);
@@ -563,6 +821,16 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.jt = value;
         return 0;
     }
+    if (!strcmp(key, "k1_flat")) {
+        if (value < 0 || value > 2) return (int)hipErrorInvalidValue;
+        g_k1.flat = value;
+        return 0;
+    }
+    if (!strcmp(key, "k1_flat_cpw")) {
+        if (value < 0 || value > 64) return (int)hipErrorInvalidValue;
+        g_k1.flat_cpw = value;
+        return 0;
+    }
     return (int)hipErrorInvalidValue;
 }
 
@@ -575,6 +843,8 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
     else if (!strcmp(key, "k1_xcd_remap")) *value = g_k1.xcd_remap;
+    else if (!strcmp(key, "k1_flat")) *value = g_k1.flat;
+    else if (!strcmp(key, "k1_flat_cpw")) *value = g_k1.flat_cpw;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
@@ -589,6 +859,19 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
+    if (A == A15 && flat_eligible(dist, dist_mask, B, N, out_rows)) {
+        // one contiguous pair range when every output row is computed, else one range per structure
+        if (rows == out_rows)
+            return launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, 0u,
+                                   (unsigned)((unsigned long long)B * out_rows * N), s);
+        for (int b = 0; b < B; ++b) {
+            const unsigned long long r0 = (unsigned long long)b * out_rows + (unsigned)(row_begin - out_row_origin);
+            const int rc = launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin,
+                                           (unsigned)(r0 * N), (unsigned)((r0 + rows) * N), s);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if (A == A15) {
         if ((rows + g_k1.rows_per_block - 1) / g_k1.rows_per_block > 65535) return (int)hipErrorInvalidValue;
         const int jt = g_k1.jt ? g_k1.jt : (N >= 256 ? 128 : 64);

@@ -133,6 +133,63 @@ def test_k1_store_policy_variants_agree(SB):
         _lib.set_tuning("k1_jt", jt0)
 
 
+def test_k1_flat_kernel_bit_identical_to_slot_decode(SB):
+    """The flat pattern kernel (any N >= 16) against the slot-decode kernel: same bits, nothing written outside the
+    requested rows, for full / compact / in-place row ranges, chunks that span rows and structures, NaN atoms."""
+    from protstruc_amd import _lib, ops
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    SENT = 12345.0
+    try:
+        for (B, N) in [(1, 16), (3, 17), (2, 18), (5, 19), (2, 37), (3, 100), (2, 127), (2, 128), (1, 437), (2, 250)]:
+            xyz, mask = synth(100 + N, B, N)
+            xyz[0, N // 3] = float("nan")
+            mask[0, N // 3] = False
+            xg, mg = xyz.cuda(), mask.cuda()
+            _lib.set_tuning("k1_variant", 1)
+            ref_d, ref_m = ops.pairwise_distance(xg, mg)
+            ref_d0, _ = ops.pairwise_distance(xg, None)
+            _lib.set_tuning("k1_variant", 0)
+            _lib.set_tuning("k1_flat", 2)
+            numel = ref_d.numel()
+            for cpw, nt in [(1, 0), (2, 0), (5, 1)]:
+                _lib.set_tuning("k1_flat_cpw", cpw)
+                _lib.set_tuning("k1_store_nt", nt)
+                # full matrix, written into the middle of a larger sentinel buffer (16-byte aligned offset)
+                pad = 64
+                bd = torch.full((numel + 2 * pad,), SENT, device="cuda")
+                bm = torch.full((numel + 2 * pad,), 7, dtype=torch.uint8, device="cuda")
+                d = bd[pad:pad + numel].view(ref_d.shape)
+                m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
+                ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+                assert torch.equal(d.view(torch.int32), ref_d.view(torch.int32)), (B, N, cpw)
+                assert torch.equal(m, ref_m), (B, N, cpw)
+                assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
+                assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
+                d0, _ = ops.pairwise_distance(xg, None, want_mask=False)
+                assert torch.equal(d0.view(torch.int32), ref_d0.view(torch.int32))
+                _, m1 = ops.pairwise_distance(xg, mg, want_dist=False)
+                assert torch.equal(m1, ref_m)
+                # row ranges: compact buffer, and in place inside a full-size buffer whose other rows stay untouched
+                for r0, r1 in [(0, 1), (1, N - 1), (N // 2, N), (N - 1, N)]:
+                    if r0 >= r1:
+                        continue
+                    cd, cm = ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, compact=True)
+                    assert torch.equal(cd.view(torch.int32), ref_d[:, r0:r1].contiguous().view(torch.int32))
+                    assert torch.equal(cm, ref_m[:, r0:r1])
+                    fd = torch.full_like(ref_d, SENT)
+                    fm = torch.full(ref_m.shape, 7, dtype=torch.uint8, device="cuda")
+                    ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, out_dist=fd, out_mask=fm.view(torch.bool))
+                    assert torch.equal(fd[:, r0:r1].contiguous().view(torch.int32),
+                                       ref_d[:, r0:r1].contiguous().view(torch.int32)), (B, N, r0, r1)
+                    assert torch.equal(fm[:, r0:r1].view(torch.bool), ref_m[:, r0:r1])
+                    assert (fd[:, :r0] == SENT).all() and (fd[:, r1:] == SENT).all()
+                    assert (fm[:, :r0] == 7).all() and (fm[:, r1:] == 7).all()
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+
+
 def test_k1_autotune_is_transparent(SB):
     """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
     from protstruc_amd import _lib, ops

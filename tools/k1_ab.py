@@ -6,13 +6,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"   # this harness sets every knob itself
 import torch
 from protstruc_amd import _lib, ops
-B, N, A = 64, 512, 15
+B, N, A = int(os.environ.get("K1_B", "64")), int(os.environ.get("K1_N", "512")), 15
 g = torch.Generator().manual_seed(0)
 xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9); mask[:, :, :3] = True; mask = mask.cuda()
 dist = torch.empty(B, N, N, A, A, device="cuda")
 dmask = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0, xcd_remap=1)
+DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0, xcd_remap=1, flat=1,
+               flat_cpw=1)
 cfgs = []
 for arg in sys.argv[1:]:
     c = dict(DEFAULT)
