@@ -269,6 +269,32 @@ def test_k1_large_n_2048(SB):
     assert torch.equal(cd, d[:, 1280:1536]) and torch.equal(cm, m[:, 1280:1536])
 
 
+def test_k1_config4_full_size_properties(SB):
+    """BASELINE config 4 at full size on one GPU (B=32, N=2048: 134 M pairs, 151 GB of output -- the largest shape
+    BASELINE names): sampled blocks against the oracle's formula, exact mask checksum per structure, symmetry."""
+    from protstruc_amd import ops
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 170 * 2**30:
+        pytest.skip("needs 170 GB of free HBM")
+    B, N = 32, 2048
+    xyz, mask = synth(0, B, N)
+    d, m = ops.pairwise_distance(xyz.cuda(), mask.cuda())
+    g = torch.Generator().manual_seed(1)
+    bs = torch.randint(0, B, (128,), generator=g)
+    is_ = torch.cat([torch.randint(0, N, (124,), generator=g), torch.tensor([0, N - 1, N - 1, 0])])
+    js = torch.cat([torch.randint(0, N, (124,), generator=g), torch.tensor([0, N - 1, 0, N - 1])])
+    want = torch.norm(xyz[bs, is_][:, :, None, :] - xyz[bs, js][:, None, :, :], dim=-1)
+    assert_close(d[bs.cuda(), is_.cuda(), js.cuda()], want)
+    assert torch.equal(m[bs.cuda(), is_.cuda(), js.cuda()].cpu(), mask[bs, is_][:, :, None] & mask[bs, js][:, None, :])
+    per_struct = mask.reshape(B, -1).sum(1).to(torch.int64)
+    got = torch.stack([torch.count_nonzero(m[b]) for b in range(B)]).cpu()
+    assert torch.equal(got, per_struct * per_struct)
+    assert torch.equal(d[B - 1, :256, 1024:1280], d[B - 1, 1024:1280, :256].permute(1, 0, 3, 2))
+    del d, m
+    torch.cuda.empty_cache()
+
+
 # ----------------------------------------------------------------------------- K2
 @pytest.mark.parametrize("name", ["g2_bbdih_chains", "g2_bbdih_padded_nan", "g2_bbdih_default_a25"])
 def test_k2_golden(SB, name):
