@@ -41,7 +41,7 @@ def _worker(rank, world, port, n_res, gather, q):
         out_m = torch.zeros(2, n_res, n_res, 15, 15, dtype=torch.bool)
         d, m, (lo, hi) = D.pairwise_distance_matrix_sharded(xyz, mask, gather=gather, out_dist=out_d, out_mask=out_m)
         rd, rm = O.pairwise_distance_matrix(xyz, mask)
-        assert (lo, hi) == D.shard_rows(n_res, rank, world)
+        assert (lo, hi) == ((0, n_res) if gather == "recompute" else D.shard_rows(n_res, rank, world))
         if gather:
             ok = torch.equal(d, rd) and torch.equal(m, rm)
         else:
@@ -54,7 +54,7 @@ def _worker(rank, world, port, n_res, gather, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_res,gather", [(8, True), (7, True), (8, False)])
+@pytest.mark.parametrize("n_res,gather", [(8, True), (7, True), (8, False), (9, "recompute")])
 def test_row_sharded_distance_world2(n_res, gather):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -67,7 +67,10 @@ def test_row_sharded_distance_world2(n_res, gather):
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(2))
     assert all(ok for _, ok, _, _ in got)
-    assert got[0][2] == 0 and got[0][3] == got[1][2] and got[1][3] == n_res  # shards tile [0, N)
+    if gather == "recompute":
+        assert all((lo, hi) == (0, n_res) for _, _, lo, hi in got)  # every rank holds all rows, no collective
+    else:
+        assert got[0][2] == 0 and got[0][3] == got[1][2] and got[1][3] == n_res  # shards tile [0, N)
 
 
 def test_shard_rows_partition():
