@@ -3,7 +3,7 @@
 
 N % 16 == 0 takes the pattern kernel, every other N >= 16 the flat pattern kernel (k1_flat=0 sends those to the
 slot-decode kernel instead).  Arguments: lengths, and key=value K1 tuning (flat=0, flat_cpw=2, ...).  Prints ms per launch and TB/s of algorithmic stores for each N at a fixed
-number of output bytes (B chosen so that B*N*N stays near 64*512*512)."""
+number of output bytes (B chosen so that B*N*N stays near 64*512*512; K1_B=<n> in the environment fixes B instead)."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +18,7 @@ lengths = [int(v) for v in sys.argv[1:] if "=" not in v] or [512, 511, 510, 508,
                                                              100, 64, 50, 33, 17]
 g = torch.Generator().manual_seed(0)
 for N in lengths:
-    B = max(1, round(64 * 512 * 512 / (N * N)))
+    B = int(os.environ["K1_B"]) if "K1_B" in os.environ else max(1, round(64 * 512 * 512 / (N * N)))
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9)
     mask[:, :, :3] = True
