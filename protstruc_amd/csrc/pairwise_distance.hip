@@ -482,8 +482,9 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                                                             const uint8_t* __restrict__ amask,
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                             int B, int N, int out_rows, int out_row_origin,
-                                                            unsigned pbeg, unsigned pend, unsigned n_chunks,
-                                                            int cpw, int xcd_remap, double rcpN_d, double rcpR_d) {
+                                                            unsigned pbeg, unsigned pend, unsigned n_ranges,
+                                                            unsigned range_stride, unsigned cpr, int cpw,
+                                                            int xcd_remap, double rcpN_d, double rcpR_d) {
     __shared__ __attribute__((aligned(16))) float4 sxj[FL * RS];
     __shared__ __attribute__((aligned(16))) float4 sxi[FR * RS];
     __shared__ uint32_t smj[FL], smi[FR], smc[FL];
@@ -495,16 +496,25 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
         w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
     }
     const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
-    const unsigned c_first = pbeg >> 7;
     const int pl = tid >> 4, c16 = tid & 15;  // staging: 16 lanes per residue
 
+    // The launch covers n_ranges pair ranges [pbeg, pend) + r * range_stride (one range, or the same rows of every
+    // structure of a row-sharded launch), each cut into at most cpr chunks on the 128-pair grid.
+    const unsigned n_chunks = n_ranges * cpr;
     for (int cc = 0; cc < cpw; ++cc) {
         const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
         if (chunk >= n_chunks) break;  // uniform
         if (cc) __syncthreads();       // the previous chunk's LDS image is still being read
-        const unsigned P0 = (c_first + chunk) << 7;
-        const int lo = pbeg > P0 ? (int)(pbeg - P0) : 0;
-        const int hi = pend - P0 < (unsigned)FL ? (int)(pend - P0) : FL;
+        unsigned rg = 0, k = chunk;
+        if (n_ranges > 1) {
+            rg = chunk / cpr;
+            k = chunk - rg * cpr;
+        }
+        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
+        const unsigned P0 = ((rbeg >> 7) + k) << 7;
+        if (P0 >= rend) continue;  // uniform: cpr is an upper bound when ranges start at different phases
+        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
+        const int hi = rend - P0 < (unsigned)FL ? (int)(rend - P0) : FL;
         // row / structure of the chunk's first pair: exact via fp64 (P0 < 2^32) with a +-1 fix-up
         unsigned R0 = (unsigned)((double)P0 * rcpN_d);
         if (R0 * (unsigned long long)N > P0) --R0;
@@ -757,17 +767,21 @@ bool flat_eligible(const float* dist, const uint8_t* dmask, int B, int N, int ou
 }
 
 int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int out_rows,
-                    int out_row_origin, unsigned pbeg, unsigned pend, hipStream_t s) {
-    if (pbeg >= pend) return 0;
-    const unsigned n_chunks = ((pend + (FL - 1)) >> 7) - (pbeg >> 7);
+                    int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges, unsigned range_stride,
+                    hipStream_t s) {
+    if (pbeg >= pend || n_ranges == 0) return 0;
+    // chunks per range: exact for one range, an upper bound when the ranges start at different 128-pair phases
+    const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> 7) - (pbeg >> 7) : ((pend - pbeg) >> 7) + 2;
+    const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
+    if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     // four chunks per workgroup are 1-2 % faster once there are plenty of workgroups (profiles/r01_k1_n_sweep.log)
     const unsigned cpw = g_k1.flat_cpw ? (unsigned)g_k1.flat_cpw : (n_chunks >= 16384u ? 4u : 1u);
-    const unsigned n_wg = (n_chunks + cpw - 1) / cpw;
+    const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
     const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_FLAT(NT_, HM_)                                                                                       \
     hipLaunchKernelGGL((k1_pairdist_a15_flat<NT_, HM_>), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N, \
-                       out_rows, out_row_origin, pbeg, pend, n_chunks, (int)cpw, remap, rn, rr)
+                       out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
     if (g_k1.store_nt) {
         if (amask) PS_K1_FLAT(true, true);
         else PS_K1_FLAT(true, false);
@@ -860,17 +874,13 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
     if (A == A15 && flat_eligible(dist, dist_mask, B, N, out_rows)) {
-        // one contiguous pair range when every output row is computed, else one range per structure
+        // one contiguous pair range when every output row is computed, else the same rows of every structure
         if (rows == out_rows)
             return launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, 0u,
-                                   (unsigned)((unsigned long long)B * out_rows * N), s);
-        for (int b = 0; b < B; ++b) {
-            const unsigned long long r0 = (unsigned long long)b * out_rows + (unsigned)(row_begin - out_row_origin);
-            const int rc = launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin,
-                                           (unsigned)(r0 * N), (unsigned)((r0 + rows) * N), s);
-            if (rc) return rc;
-        }
-        return 0;
+                                   (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
+        const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
+        return launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
+                               r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
     }
     if (A == A15) {
         if ((rows + g_k1.rows_per_block - 1) / g_k1.rows_per_block > 65535) return (int)hipErrorInvalidValue;
