@@ -48,7 +48,7 @@ struct K1Tuning {
     int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
     int flat = 1;             // flat pattern kernel: 0 never, 1 for lengths the pattern kernel cannot take (N % 16 != 0), 2 always
-    int flat_cpw = 0;         // flat kernel: consecutive 128-pair chunks per workgroup; 0 = auto (4 on large launches, else 1)
+    int flat_cpw = 1;         // flat kernel: consecutive 128-pair chunks per workgroup (autotuned per device by ops.py)
 };
 K1Tuning g_k1;
 
@@ -774,8 +774,9 @@ int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t
     const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> 7) - (pbeg >> 7) : ((pend - pbeg) >> 7) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    // four chunks per workgroup are 1-2 % faster once there are plenty of workgroups (profiles/r01_k1_n_sweep.log)
-    const unsigned cpw = g_k1.flat_cpw ? (unsigned)g_k1.flat_cpw : (n_chunks >= 16384u ? 4u : 1u);
+    // like rows_per_block this is a per-device matter: four chunks per workgroup are 1-2 % faster on some GPUs and
+    // 8 % slower on others (profiles/r01_k1_ab_flat_cpw.log), so the default is 1 and ops.py autotunes it
+    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g_k1.flat_cpw : 1u;
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
     const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
@@ -841,7 +842,7 @@ int ps_k1_set_tuning(const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "k1_flat_cpw")) {
-        if (value < 0 || value > 64) return (int)hipErrorInvalidValue;
+        if (value < 1 || value > 64) return (int)hipErrorInvalidValue;
         g_k1.flat_cpw = value;
         return 0;
     }

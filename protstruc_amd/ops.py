@@ -52,27 +52,37 @@ def _stream(t: torch.Tensor):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-# ---- one-time, per-device choice of K1's rows-per-workgroup -------------------------------------------------
+# ---- one-time, per-device choice of K1's output granule per workgroup ----------------------------------------
 # MI355X devices differ: with the XCD-contiguous workgroup map, 2-4 residue rows per workgroup run at ~6.25 TB/s
-# on some GPUs and at 4.9-5.4 TB/s on others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log).
-# The first large eligible call therefore times the candidates on the caller's own buffers (results are identical
-# for every setting) and keeps the fastest for this process.  Never runs during stream capture.
+# on some GPUs and at 4.9-5.4 TB/s on others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log);
+# the flat kernel's chunks-per-workgroup behaves the same way (+1-2 % / -8 %).  The first large call of each kind
+# therefore times the candidates on the caller's own buffers (results are identical for every setting) and keeps
+# the fastest for this process.  Never runs during stream capture.
 _K1_TUNED = {}
 _K1_CANDIDATE_ROWS = (1, 2, 4)
+_K1_CANDIDATE_CPW = (1, 2, 4)
 
 
 def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
     import os
 
-    if device in _K1_TUNED or A != 15 or N % 16 != 0 or n_pairs < (1 << 22):
+    if A != 15 or N < 16 or n_pairs < (1 << 22):
+        return
+    # which kernel this shape takes decides which knob is tuned (pairwise_distance.hip: flat_eligible)
+    pattern = (N % 16 == 0)
+    knob, result_key, ms_key, candidates = (("k1_rows_per_block", "rows_per_block", "ms", _K1_CANDIDATE_ROWS) if pattern
+                                            else ("k1_flat_cpw", "flat_cpw", "flat_ms", _K1_CANDIDATE_CPW))
+    if result_key in _K1_TUNED.get(device, {}):
         return
     if os.environ.get("PROTSTRUC_AMD_NO_AUTOTUNE") or torch.cuda.is_current_stream_capturing():
+        return
+    if not pattern and (_lib.get_tuning("k1_flat") == 0 or _lib.get_tuning("k1_variant") != 0):
         return
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
-    def launch(rows):
-        _lib.set_tuning("k1_rows_per_block", rows)
+    def launch(value):
+        _lib.set_tuning(knob, value)
         _lib.check(lib.ps_pairwise_distance_f32(*args, stream), "ps_pairwise_distance_f32 (autotune)")
 
     # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
@@ -81,23 +91,23 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
     while time.perf_counter() < t_end:
         launch(1)
         torch.cuda.current_stream(device).synchronize()
-    timings = {rows: float("inf") for rows in _K1_CANDIDATE_ROWS}
+    timings = {v: float("inf") for v in candidates}
     for _ in range(3):
-        for rows in _K1_CANDIDATE_ROWS:
-            launch(rows)
+        for v in candidates:
+            launch(v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(rows)
-            launch(rows)
+            launch(v)
+            launch(v)
             e1.record()
             e1.synchronize()
-            timings[rows] = min(timings[rows], e0.elapsed_time(e1) / 2)
-    best_rows, best_ms = 1, timings[1]
-    for rows in _K1_CANDIDATE_ROWS[1:]:
-        if timings[rows] < best_ms * 0.985:   # prefer fewer rows unless the gain is clear
-            best_rows, best_ms = rows, timings[rows]
-    _lib.set_tuning("k1_rows_per_block", best_rows)
-    _K1_TUNED[device] = {"rows_per_block": best_rows, "ms": timings}
+            timings[v] = min(timings[v], e0.elapsed_time(e1) / 2)
+    best, best_ms = 1, timings[1]
+    for v in candidates[1:]:
+        if timings[v] < best_ms * 0.985:   # prefer the small granule unless the gain is clear
+            best, best_ms = v, timings[v]
+    _lib.set_tuning(knob, best)
+    _K1_TUNED.setdefault(device, {}).update({result_key: best, ms_key: timings})
 
 
 def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,

@@ -219,6 +219,32 @@ def test_k1_autotune_is_transparent(SB):
         _lib.set_tuning("k1_rows_per_block", rows0)
 
 
+def test_k1_flat_autotune_is_transparent(SB):
+    """Same for the flat kernel's chunks-per-workgroup (lengths that are not a multiple of 16)."""
+    from protstruc_amd import _lib, ops
+    xyz, mask = synth(13, 23, 437)   # 4.39 M pairs
+    xg, mg = xyz.cuda(), mask.cuda()
+    saved = ops._K1_TUNED.pop(xg.device, None)
+    cpw0 = _lib.get_tuning("k1_flat_cpw")
+    try:
+        import os
+        os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"
+        _lib.set_tuning("k1_flat_cpw", 1)
+        d0, m0 = ops.pairwise_distance(xg, mg)
+        assert ops.k1_autotune_result(xg.device) is None
+        del os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"]
+        d1, m1 = ops.pairwise_distance(xg, mg)
+        res = ops.k1_autotune_result(xg.device)
+        assert res is not None and res["flat_cpw"] in (1, 2, 4) and set(res["flat_ms"]) == {1, 2, 4}
+        assert "rows_per_block" not in res and _lib.get_tuning("k1_flat_cpw") == res["flat_cpw"]
+        assert torch.equal(d0.view(torch.int32), d1.view(torch.int32)) and torch.equal(m0, m1)
+    finally:
+        _lib.set_tuning("k1_flat_cpw", cpw0)
+        ops._K1_TUNED.pop(xg.device, None)
+        if saved is not None:
+            ops._K1_TUNED[xg.device] = saved
+
+
 def test_k1_headline_shape_properties(SB):
     """BASELINE headline shape B=64, N=512: too big for the CPU oracle, so check
     sampled blocks against it plus whole-tensor properties."""
