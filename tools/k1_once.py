@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run the default K1 configuration a few times (profiling target for rocprofv3)."""
+"""Run the default K1 configuration a few times (profiling target for rocprofv3).  K1_B / K1_N in the environment
+choose the shape (default 64 x 512); arguments: repetitions, then key=value tuning."""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +9,7 @@ os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
 import torch
 from protstruc_amd import _lib, ops
 
-B, N, A = 64, 512, 15
+B, N, A = int(os.environ.get("K1_B", "64")), int(os.environ.get("K1_N", "512")), 15
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
