@@ -43,7 +43,8 @@ const char* ps_error_string(int code);
  * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
  * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
  * "k1_variant" (0 = pattern kernels, 1 = slot-decode kernel everywhere), "k1_jt" (64/128, 0 = auto),
- * "k1_flat" (flat pattern kernel: 0 never, 1 where N % 16 != 0, 2 always), "k1_flat_cpw" (chunks per workgroup,
+ * "k1_flat" (flat kernels: 0 never, 1 where they are the fast path, 2 / 3 force the A = 15 / any-A flat kernel),
+ * "k1_anya_fl_log2" (any-A kernel chunk length, 0 = auto), "k1_flat_cpw" (chunks per workgroup,
  * 1..64), "k1_xcd_remap" (0/1), "k1_unroll" (0/1), "k1_lds_pad_kb" (experiment),
  * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values).
  * Not part of the drop-in surface; has no reference counterpart.

@@ -47,7 +47,9 @@ struct K1Tuning {
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
-    int flat = 1;             // flat pattern kernel: 0 never, 1 for lengths the pattern kernel cannot take (N % 16 != 0), 2 always
+    int flat = 1;             // flat kernels: 0 never; 1 where they are the fast path (A = 15 with N % 16 != 0, every other A);
+                              // 2 A = 15 flat pattern kernel always; 3 any-A flat kernel always (cross-checks)
+    int anya_fl_log2 = 0;     // any-A flat kernel: log2(pairs per chunk), 0 = auto (experiments)
     int flat_cpw = 1;         // flat kernel: consecutive 128-pair chunks per workgroup (autotuned per device by ops.py)
 };
 K1Tuning g_k1;
@@ -682,6 +684,217 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
     }
 }
 
+// ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
+// Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
+// fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
+// element into (pair position, a, c) with reciprocal multiplies and walks the other three with carries.  The mask
+// plane is built once per chunk as a BIT stream in LDS -- row (p, a) contributes m_i[a] ? bits(m_j) : 0 at bit
+// p*A*A + a*A via ds_or -- and a 16-byte mask slot is then just an aligned 16-bit half-word of that stream.
+// Replaces the element-per-lane kernel below (1.8-2.5 TB/s) wherever it applies.
+constexpr unsigned NO_RES = 0xFFFFFFFFu;
+
+template <bool NT, bool HASMASK>
+__global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
+    const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ dist,
+    uint8_t* __restrict__ dmask, int B, int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
+    unsigned n_ranges, unsigned range_stride, unsigned cpr, int fl_log2, int FRr, int cpw, int xcd_remap,
+    double rcpN_d, double rcpR_d) {
+    extern __shared__ __attribute__((aligned(16))) char smem_any[];
+    const int FLr = 1 << fl_log2;
+    const unsigned AA = (unsigned)A * (unsigned)A;
+    // LDS carve: sx[(FL + FR) * A] float4 (column residues by pair position, then the touched row residues)
+    //            | smj[FL] u64 | smi[FR] u64 | sbits[FL*AA/32 + 2] u32 | ssrc[FL + FR] u32 | srl[FL] u32
+    float4* sx = reinterpret_cast<float4*>(smem_any);
+    unsigned long long* smj = reinterpret_cast<unsigned long long*>(sx + (size_t)(FLr + FRr) * A);
+    unsigned long long* smi = smj + FLr;
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(smi + FRr);
+    const unsigned nwords = ((unsigned)FLr * AA >> 5) + 2u;
+    uint32_t* ssrc = sbits + nwords;
+    uint32_t* srl = ssrc + (FLr + FRr);
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned n = gridDim.x, x = w & 7u;
+        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
+    }
+    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows, rcpA = 1.0f / (float)A,
+                rcpAA = 1.0f / (float)AA;
+    const unsigned long long allbits = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
+    const unsigned n_chunks = n_ranges * cpr;
+
+    for (int cc = 0; cc < cpw; ++cc) {
+        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
+        if (chunk >= n_chunks) break;  // uniform
+        if (cc) __syncthreads();
+        unsigned rg = 0, k = chunk;
+        if (n_ranges > 1) {
+            rg = chunk / cpr;
+            k = chunk - rg * cpr;
+        }
+        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
+        const unsigned P0 = ((rbeg >> fl_log2) + k) << fl_log2;
+        if (P0 >= rend) continue;  // uniform
+        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
+        const int hi = rend - P0 < (unsigned)FLr ? (int)(rend - P0) : FLr;
+        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
+        if (R0 * (unsigned long long)N > P0) --R0;
+        else if ((R0 + 1ull) * N <= P0) ++R0;
+        const int j_start = (int)(P0 - R0 * (unsigned)N);
+        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
+        if (b0 * (unsigned long long)out_rows > R0) --b0;
+        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
+        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
+        const int nr = (j_start + FLr - 1) / N + 1;  // rows the chunk touches (<= FRr)
+
+        // ---- pass 1: per pair position / per row: source residue, row index, atom-mask bits ----
+        for (int t = tid; t < FLr + FRr; t += 256) {
+            unsigned res = NO_RES;
+            if (t < FLr) {
+                const unsigned x = (unsigned)(j_start + t);
+                const unsigned rl = udiv_rcp(x, (unsigned)N, rcpN);
+                const unsigned j = x - rl * (unsigned)N;
+                const unsigned bb = b0 + udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
+                srl[t] = rl;
+                if (t >= lo && t < hi) res = bb * (unsigned)N + j;
+            } else {
+                const unsigned rr = (unsigned)(t - FLr);
+                const unsigned ilr = il0 + rr;
+                const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
+                const unsigned bb = b0 + db;
+                if ((int)rr < nr && bb < (unsigned)B)
+                    res = bb * (unsigned)N + (ilr - db * (unsigned)out_rows + (unsigned)out_row_origin);
+            }
+            ssrc[t] = res;
+            if (dmask) {
+                unsigned long long bits = 0;
+                if (res != NO_RES) {
+                    if (HASMASK) {
+                        const uint8_t* m = amask + (size_t)res * A;
+                        for (int c = 0; c < A; ++c) bits |= (unsigned long long)(m[c] != 0) << c;
+                    } else {
+                        bits = allbits;
+                    }
+                }
+                (t < FLr ? smj[t] : smi[t - FLr]) = bits;
+            }
+        }
+        if (dmask)
+            for (unsigned q = tid; q < nwords; q += 256) sbits[q] = 0u;
+        __syncthreads();
+
+        // ---- pass 2: coordinates (four atoms per lane in flight), then the mask bit stream ----
+        {
+            const unsigned natoms = (unsigned)(FLr + FRr) * (unsigned)A;
+            for (unsigned base = tid; base < natoms; base += 4u * 256u) {
+                float vx[4], vy[4], vz[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned idx = base + 256u * u;
+                    vx[u] = vy[u] = vz[u] = 0.f;
+                    if (idx < natoms) {
+                        const unsigned q = udiv_rcp(idx, (unsigned)A, rcpA);
+                        const unsigned res = ssrc[q];
+                        if (res != NO_RES) {
+                            const size_t src = ((size_t)res * A + (idx - q * (unsigned)A)) * 3;
+                            vx[u] = xyz[src + 0];
+                            vy[u] = xyz[src + 1];
+                            vz[u] = xyz[src + 2];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const unsigned idx = base + 256u * u;
+                    if (idx < natoms) sx[idx] = make_float4(vx[u], vy[u], vz[u], 0.f);
+                }
+            }
+        }
+        if (dmask) {
+            const unsigned nrows = (unsigned)FLr * (unsigned)A;
+            for (unsigned idx = tid; idx < nrows; idx += 256) {
+                const unsigned p = udiv_rcp(idx, (unsigned)A, rcpA);
+                const unsigned a = idx - p * (unsigned)A;
+                const unsigned long long mi = smi[srl[p]];
+                if ((mi >> a) & 1ull) {
+                    const unsigned long long bits = smj[p];
+                    const unsigned o = p * AA + a * (unsigned)A;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t part = (uint32_t)(bits >> (32 * h));
+                        if (part) {
+                            const unsigned off = o + 32u * h, wi = off >> 5, sh = off & 31u;
+                            atomicOr(&sbits[wi], part << sh);
+                            if (sh) atomicOr(&sbits[wi + 1], part >> (32u - sh));
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        const float4* sxj = sx;
+        const float4* sxi = sx + (size_t)FLr * A;
+        if (dist) {
+            float* o = dist + (size_t)P0 * AA;
+            const unsigned nslots = ((unsigned)FLr * AA) >> 2;
+            for (unsigned sl = tid; sl < nslots; sl += 256) {
+                const unsigned e0 = 4u * sl;
+                unsigned p = udiv_rcp(e0, AA, rcpAA);
+                if ((int)p >= hi) break;  // later slots of this lane lie further on still
+                const unsigned r = e0 - p * AA;
+                unsigned a = udiv_rcp(r, (unsigned)A, rcpA);
+                unsigned c = r - a * (unsigned)A;
+                unsigned ibase = srl[p] * (unsigned)A, jbase = p * (unsigned)A;
+                float v[4];
+                int pk[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    pk[kk] = (int)p;
+                    v[kk] = dist_pp(sxi[ibase + a], sxj[jbase + c]);
+                    if (++c == (unsigned)A) {
+                        c = 0;
+                        if (++a == (unsigned)A) {
+                            a = 0;
+                            ++p;
+                            jbase += (unsigned)A;
+                            if ((int)p < FLr) ibase = srl[p] * (unsigned)A;
+                        }
+                    }
+                }
+                if (pk[0] >= lo && pk[3] < hi) {
+                    store16<NT>(o + e0, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                   __float_as_uint(v[3])));
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        if (pk[kk] >= lo && pk[kk] < hi) o[e0 + kk] = v[kk];
+                }
+            }
+        }
+        if (dmask) {
+            uint8_t* o = dmask + (size_t)P0 * AA;
+            const unsigned nms = ((unsigned)FLr * AA) >> 4;
+            for (unsigned ms = tid; ms < nms; ms += 256) {
+                const unsigned e0 = 16u * ms;
+                const int p_first = (int)udiv_rcp(e0, AA, rcpAA);
+                if (p_first >= hi) break;
+                const int p_last = (int)udiv_rcp(e0 + 15u, AA, rcpAA);
+                const uint32_t win = (sbits[ms >> 1] >> (16u * (ms & 1u))) & 0xFFFFu;
+                if (p_first >= lo && p_last < hi) {
+                    store16<NT>(o + e0, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
+                                                   spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
+                } else if (p_last >= lo) {
+                    for (unsigned t = 0; t < 16u; ++t) {
+                        const int pp = (int)udiv_rcp(e0 + t, AA, rcpAA);
+                        if (pp >= lo && pp < hi) o[e0 + t] = (uint8_t)((win >> t) & 1u);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
@@ -794,6 +1007,55 @@ int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t
     return ps_check_launch();
 }
 
+// Any-A flat kernel: chunk length (a power of two, >= 16 pairs) so that the LDS image stays near 40 KB.
+bool anyA_eligible(const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
+    if (g_k1.variant != 0 || g_k1.flat == 0) return false;
+    // A < 4: a chunk's output is smaller than its LDS image and the element kernel is no slower
+    if (A < 4 || A > 64 || N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
+    if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;
+    if ((unsigned long long)B * N >= 0x7FFFFFFFull) return false;  // residue indices stay 32-bit
+    if ((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15)) return false;
+    return true;
+}
+
+int launch_anyA_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int A,
+                     int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
+                     unsigned range_stride, hipStream_t s) {
+    if (pbeg >= pend || n_ranges == 0) return 0;
+    // largest power of two of pairs (16..256) whose LDS image (A float4 + A*A/8 bytes of mask bits per pair) stays
+    // under 25 KB: measured best or within 2 % of best for A = 4, 5, 8, 14, 16, 25, 37 (profiles/r01_k1_any_a.log)
+    int fl_log2 = 4;
+    while (fl_log2 < 8 && (size_t)(2 << fl_log2) * ((size_t)A * 16 + (size_t)A * A / 8) <= 25 * 1024) ++fl_log2;
+    if (g_k1.anya_fl_log2) fl_log2 = g_k1.anya_fl_log2;
+    const int FLr = 1 << fl_log2;
+    const int FRr = (FLr - 1) / N + 2;
+    const unsigned AA = (unsigned)A * A;
+    const size_t lds = (size_t)(FLr + FRr) * A * sizeof(float4) + (size_t)(FLr + FRr) * 8 +
+                       ((size_t)(FLr * AA >> 5) + 2) * 4 + (size_t)(FLr + FRr) * 4 + (size_t)FLr * 4;
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    const unsigned cpr = n_ranges == 1 ? ((pend + (FLr - 1)) >> fl_log2) - (pbeg >> fl_log2)
+                                       : ((pend - pbeg) >> fl_log2) + 2;
+    const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
+    if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g_k1.flat_cpw : 1u;
+    const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
+    const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
+#define PS_K1_ANYA(NT_, HM_)                                                                                        \
+    hipLaunchKernelGGL((k1_pairdist_anyA_flat<NT_, HM_>), dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, \
+                       N, A, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, fl_log2, FRr,       \
+                       (int)cpw, remap, rn, rr)
+    if (g_k1.store_nt) {
+        if (amask) PS_K1_ANYA(true, true);
+        else PS_K1_ANYA(true, false);
+    } else {
+        if (amask) PS_K1_ANYA(false, true);
+        else PS_K1_ANYA(false, false);
+    }
+#undef PS_K1_ANYA
+    return ps_check_launch();
+}
+
 }  // namespace
 
 extern "C" int ps_k1_set_tuning(const char* key, int value);
@@ -837,8 +1099,13 @@ int ps_k1_set_tuning(const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "k1_flat")) {
-        if (value < 0 || value > 2) return (int)hipErrorInvalidValue;
+        if (value < 0 || value > 3) return (int)hipErrorInvalidValue;
         g_k1.flat = value;
+        return 0;
+    }
+    if (!strcmp(key, "k1_anya_fl_log2")) {
+        if (value != 0 && (value < 4 || value > 10)) return (int)hipErrorInvalidValue;
+        g_k1.anya_fl_log2 = value;
         return 0;
     }
     if (!strcmp(key, "k1_flat_cpw")) {
@@ -860,6 +1127,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_xcd_remap")) *value = g_k1.xcd_remap;
     else if (!strcmp(key, "k1_flat")) *value = g_k1.flat;
     else if (!strcmp(key, "k1_flat_cpw")) *value = g_k1.flat_cpw;
+    else if (!strcmp(key, "k1_anya_fl_log2")) *value = g_k1.anya_fl_log2;
     else return (int)hipErrorInvalidValue;
     return 0;
 }
@@ -874,6 +1142,14 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
+    if ((A != A15 || g_k1.flat == 3) && anyA_eligible(dist, dist_mask, B, N, A, out_rows)) {
+        if (rows == out_rows)
+            return launch_anyA_flat(xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,
+                                    (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
+        const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
+        return launch_anyA_flat(xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, r0,
+                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
+    }
     if (A == A15 && flat_eligible(dist, dist_mask, B, N, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
         if (rows == out_rows)

@@ -190,6 +190,67 @@ def test_k1_flat_kernel_bit_identical_to_slot_decode(SB):
             _lib.set_tuning(k, v)
 
 
+def _same_floats(a, b):
+    """Bit-identical where finite/inf, NaN in the same places (NaN payloads may differ between sqrt routines)."""
+    return torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(7.0).view(torch.int32),
+                                                             b.nan_to_num(7.0).view(torch.int32))
+
+
+def test_k1_any_atom_count_kernel_matches_element_kernel(SB):
+    """The vectorised any-A flat kernel against the element-per-lane kernel (k1_flat=0) for atom counts other than
+    15 -- and against the pattern kernels at A = 15 (k1_flat=3) -- over full, compact and in-place row ranges, with
+    sentinel guards around every output."""
+    from protstruc_amd import _lib, ops
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    SENT = 12345.0
+    cases = [(2, 16, 1), (3, 17, 2), (2, 33, 3), (3, 50, 4), (2, 100, 5), (2, 37, 14), (2, 64, 16), (2, 21, 25),
+             (1, 40, 37), (1, 19, 64), (2, 250, 4), (2, 37, 15), (1, 128, 15)]
+    try:
+        for (B, N, A) in cases:
+            xyz, mask = synth(300 + N + A, B, N, A=A)
+            xyz[0, N // 3] = float("nan")
+            mask[0, N // 3] = False
+            xg, mg = xyz.cuda(), mask.cuda()
+            _lib.set_tuning("k1_flat", 0 if A != 15 else 1)       # reference path: element kernel / pattern kernels
+            ref_d, ref_m = ops.pairwise_distance(xg, mg)
+            ref_d0, _ = ops.pairwise_distance(xg, None)
+            rd, rm = O.pairwise_distance_matrix(xyz, mask)
+            assert_close(ref_d, rd)
+            _lib.set_tuning("k1_flat", 3)
+            numel = ref_d.numel()
+            for cpw, nt in [(1, 0), (3, 1)]:
+                _lib.set_tuning("k1_flat_cpw", cpw)
+                _lib.set_tuning("k1_store_nt", nt)
+                pad = 64
+                bd = torch.full((numel + 2 * pad,), SENT, device="cuda")
+                bm = torch.full((numel + 2 * pad,), 7, dtype=torch.uint8, device="cuda")
+                d = bd[pad:pad + numel].view(ref_d.shape)
+                m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
+                ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+                assert _same_floats(d, ref_d), (B, N, A, cpw)
+                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw)
+                assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
+                assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
+                d0, _ = ops.pairwise_distance(xg, None, want_mask=False)
+                assert _same_floats(d0, ref_d0)
+                _, m1 = ops.pairwise_distance(xg, mg, want_dist=False)
+                assert torch.equal(m1, ref_m)
+                for r0, r1 in [(0, 1), (1, N - 1), (N // 2, N)]:
+                    cd, cm = ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, compact=True)
+                    assert _same_floats(cd, ref_d[:, r0:r1].contiguous()) and torch.equal(cm, ref_m[:, r0:r1])
+                    fd = torch.full_like(ref_d, SENT)
+                    fm = torch.full(ref_m.shape, 7, dtype=torch.uint8, device="cuda")
+                    ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, out_dist=fd, out_mask=fm.view(torch.bool))
+                    assert _same_floats(fd[:, r0:r1].contiguous(), ref_d[:, r0:r1].contiguous()), (B, N, A, r0, r1)
+                    assert torch.equal(fm[:, r0:r1].view(torch.bool), ref_m[:, r0:r1])
+                    assert (fd[:, :r0] == SENT).all() and (fd[:, r1:] == SENT).all()
+                    assert (fm[:, :r0] == 7).all() and (fm[:, r1:] == 7).all()
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+
+
 def test_k1_autotune_is_transparent(SB):
     """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
     from protstruc_amd import _lib, ops
