@@ -46,7 +46,9 @@ const char* ps_error_string(int code);
  * "k1_flat" (flat kernels: 0 never, 1 where they are the fast path, 2 / 3 force the A = 15 / any-A flat kernel),
  * "k1_anya_fl_log2" (any-A kernel chunk length, 0 = auto), "k1_flat_cpw" (chunks per workgroup,
  * 1..64), "k1_xcd_remap" (0/1), "k1_unroll" (0/1), "k1_lds_pad_kb" (experiment),
- * "k1_math" (0 = product arithmetic; 1, 2 = timing experiments that produce WRONG values).
+ * "k1_exact_sqrt" (K1 square root: 0 = hardware v_sqrt_f32, at most 1 ulp off; 1 = correctly rounded),
+ * "k1_math" (pattern-kernel experiments: 0 = product arithmetic, 1 = force the hardware sqrt, 2 = store-only timing
+ * run that produces WRONG values, 3 = the first correctly rounded routine).
  * Not part of the drop-in surface; has no reference counterpart.
  */
 int ps_set_tuning(const char* key, int value);

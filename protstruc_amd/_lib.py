@@ -84,6 +84,9 @@ def load():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
+    # K1 uses the hardware square root (<= 1 ulp) unless the user asks for the correctly rounded one
+    if os.environ.get("PROTSTRUC_AMD_EXACT_SQRT", "0") not in ("", "0"):
+        lib.ps_set_tuning(b"k1_exact_sqrt", 1)
     return lib
 
 

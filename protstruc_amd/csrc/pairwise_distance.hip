@@ -40,10 +40,12 @@ struct K1Tuning {
     // wave and want to merge in L2), and one row per workgroup (small granules written in address order)
     // beats 4..16 rows.
     int store_nt = 0;
+    int exact_sqrt = 0;       // 0: hardware sqrt (<= 1 ulp); 1: correctly rounded (see dist_pp)
     int rows_per_block = 1;   // IR
     int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
     int jt = 0;               // column residues per tile: 64, 128, or 0 = auto (128 when N >= 256: ~1 % faster at N = 512)
-    int math = 0;             // 0: product arithmetic; 1 / 2: timing experiments (raw sqrt / store-only), WRONG results
+    int math = 0;             // experiments on the pattern kernel: 0 product arithmetic (sqrt per exact_sqrt); 1 force the
+                              // hardware sqrt; 2 store-only (WRONG values); 3 the first correctly rounded routine
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
     int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
@@ -65,10 +67,16 @@ __device__ __forceinline__ void store16(void* p, uint4 v) {
         *reinterpret_cast<u32x4_t*>(p) = w;
 }
 
+// EXACT = false: the hardware square root (v_sqrt_f32: exact for 84.95 % of all inputs, 1 ulp off for the rest,
+// never more -- tools/microbench/sqrt_check.hip; the reference's own torch.norm is 1 ulp away from this formula on
+// ~11 % of entries).  EXACT = true: correctly rounded (sqrt_rn_mk), 22 more VALU instructions per 16-byte slot, which
+// on the devices that can store at 7 TB/s costs 10-16 % of K1's speed (profiles/r01_k1_ab_sqrt_mk.log).
+template <bool EXACT>
 __device__ __forceinline__ float dist_pp(float4 p, float4 q) {
     float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
     float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    return sqrt_rn_pos((sx + sy) + sz);
+    const float x = (sx + sy) + sz;
+    return EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
 }
 
 // four bits -> four bytes of 0/1 (bit k lands in byte k)
@@ -78,7 +86,7 @@ __device__ __forceinline__ uint32_t spread4(uint32_t nib) { return (nib * 0x0020
 // DA / MA: every (i, j-tile) run of the distance / mask plane starts on a 16-byte
 // boundary and is a whole number of 16-byte slots (N % 4 == 0 resp. N % 16 == 0
 // and an aligned base pointer) -- the branch-free path.
-template <int JT, bool NT, bool DA, bool MA>
+template <int JT, bool NT, bool DA, bool MA, bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_a15(const float* __restrict__ xyz,
                                                        const uint8_t* __restrict__ amask,
                                                        float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15(const float* __restrict__
                     float v[4];
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        v[t] = dist_pp(sxi[ia], sxj[ja]);
+                        v[t] = dist_pp<EXACT>(sxi[ia], sxj[ja]);
                         // advance (a, c) -> next element; carries are selects, not branches
                         const bool wc = (c == A15 - 1);
                         const bool wa = wc && (a == A15 - 1);
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15(const float* __restrict__
                 for (int t = 0; t < 4; ++t) {
                     const int e = e0 + t;
                     if (e >= 0 && (unsigned)e < nE) {
-                        v[t] = dist_pp(sxi[ia], sxj[ja]);
+                        v[t] = dist_pp<EXACT>(sxi[ia], sxj[ja]);
                         ++c;
                         ++ja;
                         if (c == A15) {
@@ -304,14 +312,16 @@ __device__ __forceinline__ float4 lds_atom(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// MATH: 0 = product arithmetic (correctly rounded sqrt, no contraction);
-//       1, 2 = timing experiments only (tools/k1_probe.py): raw v_sqrt_f32 / stores without any arithmetic.
+// MATH: 0 = product arithmetic with the hardware sqrt, 1 = with the correctly rounded sqrt (k1_exact_sqrt);
+//       2 = timing experiment only: stores without any arithmetic (WRONG values);
+//       3 = the first correctly rounded routine (v_sqrt + residual tests; same values as 1).
 template <int MATH>
 __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
-    if (MATH == 0) return dist_pp(p, q);
+    if (MATH == 0) return dist_pp<false>(p, q);
+    if (MATH == 1) return dist_pp<true>(p, q);
     float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
     float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    return __builtin_amdgcn_sqrtf((sx + sy) + sz);
+    return sqrt_rn_pos((sx + sy) + sz);  // MATH == 3: the first correctly rounded routine (same values as 1)
 }
 
 template <int JT, bool NT, int MATH, bool UNROLL>
@@ -479,7 +489,7 @@ __device__ __forceinline__ unsigned udiv_rcp(unsigned x, unsigned d, float rcp) 
     return q;
 }
 
-template <bool NT, bool HASMASK>
+template <bool EXACT, bool HASMASK>
 __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __restrict__ xyz,
                                                             const uint8_t* __restrict__ amask,
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -627,11 +637,11 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                         const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
                         const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
                         uint4 u;
-                        u.x = __float_as_uint(dist_pp(pi[0], q0));
-                        u.y = __float_as_uint(dist_pp(pi[1], q1));
-                        u.z = __float_as_uint(dist_pp(pi[2], q2));
-                        u.w = __float_as_uint(dist_pp(pi[3], q3));
-                        store16<NT>(o + (size_t)(g + q) * (4 * AA15), u);
+                        u.x = __float_as_uint(dist_pp<EXACT>(pi[0], q0));
+                        u.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
+                        u.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
+                        u.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
+                        store16<false>(o + (size_t)(g + q) * (4 * AA15), u);
                     }
                     g += nfast;
                     continue;
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                             const int rk = rl + (pp >= nb ? 1 : 0);  // N >= 16: at most one row change per group
                             const float4 xi = sxi[rk * RS + ai[k]];
                             const float4 xq = sxj[g * (4 * RS) + offj[k]];
-                            o[(size_t)g * (4 * AA15) + k] = dist_pp(xi, xq);
+                            o[(size_t)g * (4 * AA15) + k] = dist_pp<EXACT>(xi, xq);
                         }
                     }
                 }
@@ -671,7 +681,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                     if (pg >= lo && pg + 16 <= hi) {
                         uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
                                              spread4((win >> 12) & 15u));
-                        store16<NT>(o + (size_t)g * (16 * AA15), u);
+                        store16<false>(o + (size_t)g * (16 * AA15), u);
                     } else {
                         for (unsigned t = 0; t < 16u; ++t) {
                             const int pp = pg + (int)((c + t < (unsigned)A15) ? jo : jo1);
@@ -693,7 +703,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
 // Replaces the element-per-lane kernel below (1.8-2.5 TB/s) wherever it applies.
 constexpr unsigned NO_RES = 0xFFFFFFFFu;
 
-template <bool NT, bool HASMASK>
+template <bool EXACT, bool HASMASK>
 __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ dist,
     uint8_t* __restrict__ dmask, int B, int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
@@ -851,7 +861,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     pk[kk] = (int)p;
-                    v[kk] = dist_pp(sxi[ibase + a], sxj[jbase + c]);
+                    v[kk] = dist_pp<EXACT>(sxi[ibase + a], sxj[jbase + c]);
                     if (++c == (unsigned)A) {
                         c = 0;
                         if (++a == (unsigned)A) {
@@ -863,7 +873,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
                     }
                 }
                 if (pk[0] >= lo && pk[3] < hi) {
-                    store16<NT>(o + e0, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                    store16<false>(o + e0, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                                    __float_as_uint(v[3])));
                 } else {
 #pragma unroll
@@ -882,7 +892,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
                 const int p_last = (int)udiv_rcp(e0 + 15u, AA, rcpAA);
                 const uint32_t win = (sbits[ms >> 1] >> (16u * (ms & 1u))) & 0xFFFFu;
                 if (p_first >= lo && p_last < hi) {
-                    store16<NT>(o + e0, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
+                    store16<false>(o + e0, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
                                                    spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
                 } else if (p_last >= lo) {
                     for (unsigned t = 0; t < 16u; ++t) {
@@ -896,6 +906,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
 }
 
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
                                                            const uint8_t* __restrict__ amask,
                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -918,7 +929,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restri
         if (dist) {
             float dx = xa[0] - xj[0], dy = xa[1] - xj[1], dz = xa[2] - xj[2];
             float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-            dist[obase + e] = sqrtf((sx + sy) + sz);
+            const float x = (sx + sy) + sz;
+            dist[obase + e] = EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
         }
         if (dmask) {
             uint8_t v = 1;
@@ -937,9 +949,14 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     size_t lds = (size_t)(JT + IR) * A15 * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
     const bool da = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
     const bool ma = (N % 16 == 0) && ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0);
-#define PS_K1_LAUNCH(NT_, DA_, MA_)                                                                                  \
-    hipLaunchKernelGGL((k1_pairdist_a15<JT, NT_, DA_, MA_>), grid, dim3(256), lds, s, xyz, amask, dist, dmask, N,    \
+#define PS_K1_LAUNCH1(NT_, DA_, MA_, EX_)                                                                            \
+    hipLaunchKernelGGL((k1_pairdist_a15<JT, NT_, DA_, MA_, EX_>), grid, dim3(256), lds, s, xyz, amask, dist, dmask, N, \
                        row_begin, row_end, out_rows, out_row_origin, IR)
+#define PS_K1_LAUNCH(NT_, DA_, MA_)                                                                                  \
+    do {                                                                                                             \
+        if (g_k1.exact_sqrt) PS_K1_LAUNCH1(NT_, DA_, MA_, true);                                                     \
+        else PS_K1_LAUNCH1(NT_, DA_, MA_, false);                                                                    \
+    } while (0)
     if (da && ma && g_k1.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
                                (size_t)g_k1.lds_pad_kb * 1024;
@@ -950,11 +967,16 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
     hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), dim3((unsigned)n_wg), dim3(256), lds_pat, s, xyz,    \
                        amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, (int)grid.x,       \
                        (int)grid.y, remap)
-        if (g_k1.math == 1) PS_K1_PAT(false, 1, false);
+        const bool ex = g_k1.exact_sqrt != 0;
+        if (g_k1.math == 1) PS_K1_PAT(false, 0, false);
+        else if (g_k1.math == 3) PS_K1_PAT(false, 3, false);
         else if (g_k1.math == 2 && g_k1.unroll) PS_K1_PAT(false, 2, true);
         else if (g_k1.math == 2) PS_K1_PAT(false, 2, false);
+        else if (g_k1.store_nt && ex) PS_K1_PAT(true, 1, false);
         else if (g_k1.store_nt) PS_K1_PAT(true, 0, false);
+        else if (g_k1.unroll && ex) PS_K1_PAT(false, 1, true);
         else if (g_k1.unroll) PS_K1_PAT(false, 0, true);
+        else if (ex) PS_K1_PAT(false, 1, false);
         else PS_K1_PAT(false, 0, false);
 #undef PS_K1_PAT
     } else if (da && ma) {
@@ -966,6 +988,7 @@ int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dma
         PS_K1_LAUNCH(true, false, false);
     }
 #undef PS_K1_LAUNCH
+#undef PS_K1_LAUNCH1
     return ps_check_launch();
 }
 
@@ -993,10 +1016,10 @@ int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
     const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
-#define PS_K1_FLAT(NT_, HM_)                                                                                       \
-    hipLaunchKernelGGL((k1_pairdist_a15_flat<NT_, HM_>), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N, \
+#define PS_K1_FLAT(EX_, HM_)                                                                                       \
+    hipLaunchKernelGGL((k1_pairdist_a15_flat<EX_, HM_>), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N, \
                        out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
-    if (g_k1.store_nt) {
+    if (g_k1.exact_sqrt) {
         if (amask) PS_K1_FLAT(true, true);
         else PS_K1_FLAT(true, false);
     } else {
@@ -1041,11 +1064,11 @@ int launch_anyA_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
     const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
-#define PS_K1_ANYA(NT_, HM_)                                                                                        \
-    hipLaunchKernelGGL((k1_pairdist_anyA_flat<NT_, HM_>), dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, \
+#define PS_K1_ANYA(EX_, HM_)                                                                                        \
+    hipLaunchKernelGGL((k1_pairdist_anyA_flat<EX_, HM_>), dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, \
                        N, A, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, fl_log2, FRr,       \
                        (int)cpw, remap, rn, rr)
-    if (g_k1.store_nt) {
+    if (g_k1.exact_sqrt) {
         if (amask) PS_K1_ANYA(true, true);
         else PS_K1_ANYA(true, false);
     } else {
@@ -1064,6 +1087,10 @@ extern "C" int ps_k1_get_tuning(const char* key, int* value);
 int ps_k1_set_tuning(const char* key, int value) {
     if (!strcmp(key, "k1_store_nt")) {
         g_k1.store_nt = value ? 1 : 0;
+        return 0;
+    }
+    if (!strcmp(key, "k1_exact_sqrt")) {
+        g_k1.exact_sqrt = value ? 1 : 0;
         return 0;
     }
     if (!strcmp(key, "k1_rows_per_block")) {
@@ -1089,7 +1116,7 @@ int ps_k1_set_tuning(const char* key, int value) {
         return 0;
     }
     if (!strcmp(key, "k1_math")) {
-        if (value < 0 || value > 2) return (int)hipErrorInvalidValue;
+        if (value < 0 || value > 3) return (int)hipErrorInvalidValue;
         g_k1.math = value;
         return 0;
     }
@@ -1118,6 +1145,7 @@ int ps_k1_set_tuning(const char* key, int value) {
 
 int ps_k1_get_tuning(const char* key, int* value) {
     if (!strcmp(key, "k1_store_nt")) *value = g_k1.store_nt;
+    else if (!strcmp(key, "k1_exact_sqrt")) *value = g_k1.exact_sqrt;
     else if (!strcmp(key, "k1_rows_per_block")) *value = g_k1.rows_per_block;
     else if (!strcmp(key, "k1_variant")) *value = g_k1.variant;
     else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
@@ -1172,7 +1200,11 @@ extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_ma
     if (nE > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
     unsigned gx = (unsigned)((nE + 255) / 256);
     if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(k1_pairdist_generic, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist, dist_mask, N, A,
-                       row_begin, row_end, out_rows, out_row_origin);
+    if (g_k1.exact_sqrt)
+        hipLaunchKernelGGL(k1_pairdist_generic<true>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
+                           dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
+    else
+        hipLaunchKernelGGL(k1_pairdist_generic<false>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
+                           dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
     return ps_check_launch();
 }

@@ -32,9 +32,11 @@ __device__ __forceinline__ float dot3(f3 a, f3 b) {
 // Correctly rounded sqrt for x >= 0 without the subnormal pre-scaling of the
 // library routine: v_sqrt_f32 is within 1 ulp, so the answer is s-1ulp, s or
 // s+1ulp and two exact fma residuals pick it.  0, inf and NaN fall through
-// unchanged (every comparison with a NaN residual is false).  A squared
-// distance below 1.2e-38 (atoms closer than 1e-19) would lose correct rounding,
-// nothing else.
+// unchanged (every comparison with a NaN residual is false).  Checked against
+// sqrtf over every float in [0, +inf] (tools/microbench/sqrt_check.hip): equal
+// for every x >= 4.6e-32; below that (atoms closer than 2e-16) the residuals
+// underflow and the result can be 1 ulp off.  Kept as the cross-check of
+// sqrt_rn_mk below, which is what the kernels use.
 __device__ __forceinline__ float sqrt_rn_pos(float x) {
     const float s = __builtin_amdgcn_sqrtf(x);
     const float lo = __uint_as_float(__float_as_uint(s) - 1u);
@@ -47,16 +49,36 @@ __device__ __forceinline__ float sqrt_rn_pos(float x) {
     return r;
 }
 
+// The same correctly rounded result from v_rsq_f32: one coupled Newton step for g ~ sqrt(x) and h ~ 1/(2 sqrt(x)),
+// then the exact-residual correction g + (x - g*g) * h (fma).  Every operation is a mul or an fma, so two elements
+// share one v_pk_* instruction: 4 + 3.5 + 2 issue slots per element against 4 + 9 for sqrt_rn_pos.  Zero, subnormal
+// and +inf inputs are returned as x (sqrt(0) = 0 and sqrt(inf) = inf exactly; a subnormal squared distance means
+// atoms closer than 1e-19, error < 1.1e-19).  Checked against sqrtf over every float in [0, +inf]
+// (tools/microbench/sqrt_check.hip): equal for every x >= 2.0e-31 (atoms further apart than 4.5e-16), at most
+// 1 ulp off below.  In K1's pattern kernel this takes the inner loop from 66 to 50 VALU instructions per 16-byte
+// slot, which is what lets it reach its store-only time (profiles/r01_k1_ab_sqrt_mk.log).
+__device__ __forceinline__ float sqrt_rn_mk(float x) {
+    const float y = __builtin_amdgcn_rsqf(x);
+    float g = x * y;
+    float h = 0.5f * y;
+    const float r = __builtin_fmaf(-h, g, 0.5f);
+    g = __builtin_fmaf(g, r, g);
+    h = __builtin_fmaf(h, r, h);
+    const float d = __builtin_fmaf(-g, g, x);
+    g = __builtin_fmaf(d, h, g);
+    return __builtin_amdgcn_classf(x, 0x2F0) ? x : g;   // +-0, +-subnormal, +inf
+}
+
 // |a - b| exactly as K1 evaluates it (protstruc.py:477-479): differences, squares, two adds, sqrt
 __device__ __forceinline__ float dist3(f3 a, f3 b) {
     float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    return sqrt_rn_pos((sx + sy) + sz);
+    return sqrt_rn_mk((sx + sy) + sz);
 }
 
 // x.norm(dim=-1) (geometry.py:29-31); correctly rounded sqrt in half the instructions of the library routine
 // (identical result unless the squared norm is subnormal, i.e. |a| < 1e-19)
-__device__ __forceinline__ float norm3(f3 a) { return sqrt_rn_pos(dot3(a, a)); }
+__device__ __forceinline__ float norm3(f3 a) { return sqrt_rn_mk(dot3(a, a)); }
 
 // np.cross component order: u1*v2 - u2*v1, ... two products then one subtract
 __device__ __forceinline__ f3 cross3(f3 u, f3 v) {

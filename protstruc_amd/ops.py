@@ -110,6 +110,17 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
     _K1_TUNED.setdefault(device, {}).update({result_key: best, ms_key: timings})
 
 
+def set_exact_sqrt(flag: bool) -> None:
+    """K1 arithmetic: False (default) = hardware square root, exact for 85 % of inputs and 1 ulp off for the rest;
+    True = correctly rounded square root (slower on devices that are not limited by their store rate).
+    ``PROTSTRUC_AMD_EXACT_SQRT=1`` in the environment selects True at load time."""
+    _lib.set_tuning("k1_exact_sqrt", 1 if flag else 0)
+
+
+def get_exact_sqrt() -> bool:
+    return bool(_lib.get_tuning("k1_exact_sqrt"))
+
+
 def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,
                                out_mask: torch.Tensor):
     """Run the one-time per-device K1 autotune now (library initialisation), on the given buffers."""

@@ -133,14 +133,16 @@ def test_k1_store_policy_variants_agree(SB):
         _lib.set_tuning("k1_jt", jt0)
 
 
-def test_k1_flat_kernel_bit_identical_to_slot_decode(SB):
+@pytest.mark.parametrize("exact", [0, 1])
+def test_k1_flat_kernel_bit_identical_to_slot_decode(SB, exact):
     """The flat pattern kernel (any N >= 16) against the slot-decode kernel: same bits, nothing written outside the
     requested rows, for full / compact / in-place row ranges, chunks that span rows and structures, NaN atoms."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
     saved = {k: _lib.get_tuning(k) for k in keys}
     SENT = 12345.0
     try:
+        _lib.set_tuning("k1_exact_sqrt", exact)
         for (B, N) in [(1, 16), (3, 17), (2, 18), (5, 19), (2, 37), (3, 100), (2, 127), (2, 128), (1, 437), (2, 250)]:
             xyz, mask = synth(100 + N, B, N)
             xyz[0, N // 3] = float("nan")
@@ -196,13 +198,15 @@ def _same_floats(a, b):
                                                              b.nan_to_num(7.0).view(torch.int32))
 
 
-def test_k1_any_atom_count_kernel_matches_element_kernel(SB):
+@pytest.mark.parametrize("exact", [0, 1])
+def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
     """The vectorised any-A flat kernel against the element-per-lane kernel (k1_flat=0) for atom counts other than
     15 -- and against the pattern kernels at A = 15 (k1_flat=3) -- over full, compact and in-place row ranges, with
     sentinel guards around every output."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
     saved = {k: _lib.get_tuning(k) for k in keys}
+    _lib.set_tuning("k1_exact_sqrt", exact)
     SENT = 12345.0
     cases = [(2, 16, 1), (3, 17, 2), (2, 33, 3), (3, 50, 4), (2, 100, 5), (2, 37, 14), (2, 64, 16), (2, 21, 25),
              (1, 40, 37), (1, 19, 64), (2, 250, 4), (2, 37, 15), (1, 128, 15)]
@@ -246,6 +250,42 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB):
                     assert torch.equal(fm[:, r0:r1].view(torch.bool), ref_m[:, r0:r1])
                     assert (fd[:, :r0] == SENT).all() and (fd[:, r1:] == SENT).all()
                     assert (fm[:, :r0] == 7).all() and (fm[:, r1:] == 7).all()
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+
+
+def test_k1_square_root_modes(SB):
+    """K1's two arithmetic modes.  Exact mode is the correctly rounded sqrt of the fp32 sum ((dx^2 + dy^2) + dz^2):
+    bit-identical to numpy evaluating that formula in float32.  The default mode uses the hardware square root: never
+    more than 1 ulp away from exact mode, identical on most entries.  Every kernel behind the entry point is covered
+    (pattern, flat pattern, slot-decode, any-A flat, element-per-lane)."""
+    from protstruc_amd import _lib, ops
+    keys = ("k1_variant", "k1_flat", "k1_exact_sqrt")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+
+    def numpy_formula(xyz):
+        x = xyz.numpy().astype(np.float32)
+        d = x[:, :, None, :, None, :] - x[:, None, :, None, :, :]
+        sq = d * d
+        return torch.from_numpy(np.sqrt((sq[..., 0] + sq[..., 1]) + sq[..., 2]))
+
+    try:
+        for (B, N, A, variant, flat) in [(2, 64, 15, 0, 1), (2, 37, 15, 0, 1), (2, 37, 15, 1, 1), (2, 40, 5, 0, 1),
+                                         (2, 40, 5, 0, 0), (1, 24, 37, 0, 1)]:
+            xyz, mask = synth(900 + N + A, B, N, A=A, scale=float(N % 7 + 1))
+            xg, mg = xyz.cuda(), mask.cuda()
+            _lib.set_tuning("k1_variant", variant)
+            _lib.set_tuning("k1_flat", flat)
+            want = numpy_formula(xyz)
+            _lib.set_tuning("k1_exact_sqrt", 1)
+            de, _ = ops.pairwise_distance(xg, mg)
+            assert torch.equal(de.cpu().view(torch.int32), want.view(torch.int32)), (B, N, A, variant, flat)
+            _lib.set_tuning("k1_exact_sqrt", 0)
+            df, _ = ops.pairwise_distance(xg, mg)
+            ulps = (df.cpu().view(torch.int32) - want.view(torch.int32)).abs()
+            assert int(ulps.max()) <= 1, (B, N, A, variant, flat)
+            assert float((ulps == 0).float().mean()) > 0.75
     finally:
         for k, v in saved.items():
             _lib.set_tuning(k, v)
@@ -725,13 +765,24 @@ def test_inter_residue_geometry_golden(SB):
 
 
 def test_inter_residue_geometry_matches_unfused_kernels(SB):
-    """The fused featuriser must equal the K1 slices and the K3 calls it replaces, bit for bit."""
+    """The fused featuriser must equal the K1 slices (K1 in its correctly rounded mode, which is what the featuriser
+    always uses; within 1 ulp of K1's default hardware-sqrt mode) and the K3 calls it replaces, bit for bit."""
+    from protstruc_amd import ops
     xyz, mask = synth(77, 3, 100)
     sb = SB.from_xyz(xyz, mask)
     geo = sb.inter_residue_geometry()
-    d, m = sb.pairwise_distance_matrix()
+    was = ops.get_exact_sqrt()
+    try:
+        ops.set_exact_sqrt(True)
+        d, m = sb.pairwise_distance_matrix()
+        ops.set_exact_sqrt(False)
+        d_hw, _ = sb.pairwise_distance_matrix()
+    finally:
+        ops.set_exact_sqrt(was)
     for key, (a, c) in {"d_ca": (1, 1), "d_cb": (4, 4), "d_no": (0, 3)}.items():
         assert torch.equal(geo[key], d[:, :, :, a, c]) and torch.equal(geo[key + "_mask"], m[:, :, :, a, c])
+        ulps = (geo[key].view(torch.int32) - d_hw[:, :, :, a, c].contiguous().view(torch.int32)).abs()
+        assert int(ulps.max()) <= 1
 
     def same(x, y):
         return torch.equal(x.isnan(), y.isnan()) and torch.equal(x.nan_to_num(0), y.nan_to_num(0))

@@ -12,7 +12,7 @@ xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9); mask[:, :, :3] = True; mask = mask.cuda()
 dist = torch.empty(B, N, N, A, A, device="cuda")
 dmask = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0, xcd_remap=1, flat=1,
+DEFAULT = dict(variant=0, jt=0, rows_per_block=1, store_nt=0, math=0, unroll=0, lds_pad_kb=0, xcd_remap=1, flat=1, exact_sqrt=0,
                flat_cpw=1)
 cfgs = []
 for arg in sys.argv[1:]:
