@@ -855,22 +855,25 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
                 const unsigned r = e0 - p * AA;
                 unsigned a = udiv_rcp(r, (unsigned)A, rcpA);
                 unsigned c = r - a * (unsigned)A;
-                unsigned ibase = srl[p] * (unsigned)A, jbase = p * (unsigned)A;
+                // A >= 4: the four elements of a slot see at most one wrap of c and touch at most two pairs, so
+                // every element's (pair, a, c) follows from the first one's with selects -- no branches, no chain
+                const unsigned p1 = min(p + 1u, (unsigned)FLr - 1u);
+                const unsigned ibase0 = srl[p] * (unsigned)A, ibase1 = srl[p1] * (unsigned)A;
+                const unsigned jbase0 = p * (unsigned)A;
                 float v[4];
                 int pk[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    pk[kk] = (int)p;
-                    v[kk] = dist_pp<EXACT>(sxi[ibase + a], sxj[jbase + c]);
-                    if (++c == (unsigned)A) {
-                        c = 0;
-                        if (++a == (unsigned)A) {
-                            a = 0;
-                            ++p;
-                            jbase += (unsigned)A;
-                            if ((int)p < FLr) ibase = srl[p] * (unsigned)A;
-                        }
-                    }
+                    unsigned ck = c + (unsigned)kk;
+                    const bool wc = ck >= (unsigned)A;
+                    ck = wc ? ck - (unsigned)A : ck;
+                    unsigned ak = a + (wc ? 1u : 0u);
+                    const bool wa = ak >= (unsigned)A;
+                    ak = wa ? 0u : ak;
+                    pk[kk] = (int)p + (wa ? 1 : 0);
+                    const unsigned ii = (wa ? ibase1 : ibase0) + ak;
+                    const unsigned jj = jbase0 + (wa ? (unsigned)A : 0u) + ck;
+                    v[kk] = dist_pp<EXACT>(sxi[ii], sxj[jj]);
                 }
                 if (pk[0] >= lo && pk[3] < hi) {
                     store16<false>(o + e0, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
