@@ -221,7 +221,7 @@ def main():
                    "global_batch": B * world, "n_res": N_RES, "n_atom": N_ATOM,
                    "parallelism": "replicas-of-batch" if world > 1 else "single-gpu",
                    "k1_tuning": {k: _lib.get_tuning(k) for k in ("k1_variant", "k1_jt", "k1_rows_per_block", "k1_store_nt",
-                                                                 "k1_xcd_remap", "k1_exact_sqrt")},
+                                                                 "k1_xcd_remap", "k1_exact_sqrt", "k1_lds_pad_kb")},
                    "k1_sqrt": ("correctly rounded" if _lib.get_tuning("k1_exact_sqrt")
                                else "hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise; parity gate 1e-5 abs)"),
                    "k1_autotune": ops.k1_autotune_result(dev)},

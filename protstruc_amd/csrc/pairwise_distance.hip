@@ -48,7 +48,8 @@ struct K1Tuning {
                               // hardware sqrt; 2 store-only (WRONG values); 3 the first correctly rounded routine
     int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
     int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
-    int lds_pad_kb = 0;       // experiment: extra dynamic LDS per workgroup to cap resident workgroups per CU
+    int lds_pad_kb = 0;       // extra (idle) dynamic LDS per workgroup: caps resident workgroups per CU; 8 KB (4 -> 3 per CU)
+                              // is an autotune candidate, worth ~2 % on the devices that dislike many concurrent streams
     int flat = 1;             // flat kernels: 0 never; 1 where they are the fast path (A = 15 with N % 16 != 0, every other A);
                               // 2 A = 15 flat pattern kernel always; 3 any-A flat kernel always (cross-checks)
     int anya_fl_log2 = 0;     // any-A flat kernel: log2(pairs per chunk), 0 = auto (experiments)

@@ -59,7 +59,9 @@ def _stream(t: torch.Tensor):
 # therefore times the candidates on the caller's own buffers (results are identical for every setting) and keeps
 # the fastest for this process.  Never runs during stream capture.
 _K1_TUNED = {}
-_K1_CANDIDATE_ROWS = (1, 2, 4)
+# pattern kernel: (rows per workgroup, KB of idle LDS per workgroup).  The LDS pad only lowers the number of resident
+# workgroups per CU (4 -> 3): on the devices that dislike large granules that is worth ~2 % (fewer concurrent streams).
+_K1_CANDIDATE_PATTERN = ((1, 0), (1, 8), (2, 0), (4, 0))
 _K1_CANDIDATE_CPW = (1, 2, 4)
 
 
@@ -70,8 +72,7 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
         return
     # which kernel this shape takes decides which knob is tuned (pairwise_distance.hip: flat_eligible)
     pattern = (N % 16 == 0)
-    knob, result_key, ms_key, candidates = (("k1_rows_per_block", "rows_per_block", "ms", _K1_CANDIDATE_ROWS) if pattern
-                                            else ("k1_flat_cpw", "flat_cpw", "flat_ms", _K1_CANDIDATE_CPW))
+    result_key = "rows_per_block" if pattern else "flat_cpw"
     if result_key in _K1_TUNED.get(device, {}):
         return
     if os.environ.get("PROTSTRUC_AMD_NO_AUTOTUNE") or torch.cuda.is_current_stream_capturing():
@@ -80,34 +81,47 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
         return
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_CPW
 
-    def launch(value):
-        _lib.set_tuning(knob, value)
+    def apply(cand):
+        if pattern:
+            _lib.set_tuning("k1_rows_per_block", cand[0])
+            _lib.set_tuning("k1_lds_pad_kb", cand[1])
+        else:
+            _lib.set_tuning("k1_flat_cpw", cand)
+
+    def launch(cand):
+        apply(cand)
         _lib.check(lib.ps_pairwise_distance_f32(*args, stream), "ps_pairwise_distance_f32 (autotune)")
 
     # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
     # then time the candidates in interleaved rounds and keep each one's minimum
     t_end = time.perf_counter() + 0.12
     while time.perf_counter() < t_end:
-        launch(1)
+        launch(candidates[0])
         torch.cuda.current_stream(device).synchronize()
-    timings = {v: float("inf") for v in candidates}
+    timings = {c: float("inf") for c in candidates}
     for _ in range(3):
-        for v in candidates:
-            launch(v)
+        for c in candidates:
+            launch(c)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            launch(v)
-            launch(v)
+            launch(c)
+            launch(c)
             e1.record()
             e1.synchronize()
-            timings[v] = min(timings[v], e0.elapsed_time(e1) / 2)
-    best, best_ms = 1, timings[1]
-    for v in candidates[1:]:
-        if timings[v] < best_ms * 0.985:   # prefer the small granule unless the gain is clear
-            best, best_ms = v, timings[v]
-    _lib.set_tuning(knob, best)
-    _K1_TUNED.setdefault(device, {}).update({result_key: best, ms_key: timings})
+            timings[c] = min(timings[c], e0.elapsed_time(e1) / 2)
+    best, best_ms = candidates[0], timings[candidates[0]]
+    for c in candidates[1:]:
+        if timings[c] < best_ms * 0.985:   # prefer the earlier (smaller-granule) candidate unless the gain is clear
+            best, best_ms = c, timings[c]
+    apply(best)
+    if pattern:
+        label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
+        _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1],
+                                                 "ms": {label[c]: timings[c] for c in candidates}})
+    else:
+        _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best, "flat_ms": timings})
 
 
 def set_exact_sqrt(flag: bool) -> None:

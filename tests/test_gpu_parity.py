@@ -297,7 +297,7 @@ def test_k1_autotune_is_transparent(SB):
     xyz, mask = synth(12, 16, 512)   # 4.2 M pairs: large enough to trigger the autotune if it has not run yet
     xg, mg = xyz.cuda(), mask.cuda()
     ops._K1_TUNED.pop(xg.device, None)
-    rows0 = _lib.get_tuning("k1_rows_per_block")
+    rows0, pad0 = _lib.get_tuning("k1_rows_per_block"), _lib.get_tuning("k1_lds_pad_kb")
     try:
         _lib.set_tuning("k1_rows_per_block", 1)
         import os
@@ -307,8 +307,9 @@ def test_k1_autotune_is_transparent(SB):
         del os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"]
         d1, m1 = ops.pairwise_distance(xg, mg)
         res = ops.k1_autotune_result(xg.device)
-        assert res is not None and res["rows_per_block"] in (1, 2, 4) and set(res["ms"]) == {1, 2, 4}
+        assert res is not None and res["rows_per_block"] in (1, 2, 4) and set(res["ms"]) == {1, "1+8KB", 2, 4}
         assert _lib.get_tuning("k1_rows_per_block") == res["rows_per_block"]
+        assert _lib.get_tuning("k1_lds_pad_kb") == res["lds_pad_kb"]
         assert torch.equal(d0, d1) and torch.equal(m0, m1)
         g = torch.cuda.CUDAGraph()            # a captured call never autotunes and still works
         ops._K1_TUNED.pop(xg.device, None)
@@ -318,6 +319,7 @@ def test_k1_autotune_is_transparent(SB):
         assert ops.k1_autotune_result(xg.device) is None and torch.equal(d2, d0)
     finally:
         _lib.set_tuning("k1_rows_per_block", rows0)
+        _lib.set_tuning("k1_lds_pad_kb", pad0)
 
 
 def test_k1_flat_autotune_is_transparent(SB):
