@@ -45,7 +45,7 @@ const char* ps_error_string(int code);
  * "k1_variant" (0 = pattern kernels, 1 = slot-decode kernel everywhere), "k1_jt" (64/128, 0 = auto),
  * "k1_flat" (flat kernels: 0 never, 1 where they are the fast path, 2 / 3 force the A = 15 / any-A flat kernel),
  * "k1_anya_fl_log2" (any-A kernel chunk length, 0 = auto), "k1_flat_cpw" (chunks per workgroup,
- * 1..64), "k1_xcd_remap" (0/1), "k1_unroll" (0/1), "k1_lds_pad_kb" (experiment),
+ * 1..64), "k1_xcd_remap" (0/1), "k1_unroll" (0/1), "k1_lds_pad_kb" / "k1_flat_lds_pad_kb" (idle LDS per workgroup = residency cap),
  * "k1_exact_sqrt" (K1 square root: 0 = hardware v_sqrt_f32, at most 1 ulp off; 1 = correctly rounded),
  * "k1_math" (pattern-kernel experiments: 0 = product arithmetic, 1 = force the hardware sqrt, 2 = store-only timing
  * run that produces WRONG values, 3 = the first correctly rounded routine).

@@ -53,6 +53,7 @@ struct K1Tuning {
     int flat = 1;             // flat kernels: 0 never; 1 where they are the fast path (A = 15 with N % 16 != 0, every other A);
                               // 2 A = 15 flat pattern kernel always; 3 any-A flat kernel always (cross-checks)
     int anya_fl_log2 = 0;     // any-A flat kernel: log2(pairs per chunk), 0 = auto (experiments)
+    int flat_lds_pad_kb = 0;  // the same residency cap for the flat pattern kernel
     int flat_cpw = 1;         // flat kernel: consecutive 128-pair chunks per workgroup (autotuned per device by ops.py)
 };
 K1Tuning g_k1;
@@ -1020,8 +1021,9 @@ int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
     const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
+    const size_t pad = (size_t)g_k1.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap (see K1Tuning)
 #define PS_K1_FLAT(EX_, HM_)                                                                                       \
-    hipLaunchKernelGGL((k1_pairdist_a15_flat<EX_, HM_>), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N, \
+    hipLaunchKernelGGL((k1_pairdist_a15_flat<EX_, HM_>), dim3(n_wg), dim3(256), pad, s, xyz, amask, dist, dmask, B, N, \
                        out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
     if (g_k1.exact_sqrt) {
         if (amask) PS_K1_FLAT(true, true);
@@ -1110,6 +1112,11 @@ int ps_k1_set_tuning(const char* key, int value) {
         g_k1.xcd_remap = value ? 1 : 0;
         return 0;
     }
+    if (!strcmp(key, "k1_flat_lds_pad_kb")) {
+        if (value < 0 || value > 100) return (int)hipErrorInvalidValue;
+        g_k1.flat_lds_pad_kb = value;
+        return 0;
+    }
     if (!strcmp(key, "k1_lds_pad_kb")) {
         if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
         g_k1.lds_pad_kb = value;
@@ -1156,6 +1163,7 @@ int ps_k1_get_tuning(const char* key, int* value) {
     else if (!strcmp(key, "k1_math")) *value = g_k1.math;
     else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
     else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
+    else if (!strcmp(key, "k1_flat_lds_pad_kb")) *value = g_k1.flat_lds_pad_kb;
     else if (!strcmp(key, "k1_xcd_remap")) *value = g_k1.xcd_remap;
     else if (!strcmp(key, "k1_flat")) *value = g_k1.flat;
     else if (!strcmp(key, "k1_flat_cpw")) *value = g_k1.flat_cpw;

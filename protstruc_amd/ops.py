@@ -62,7 +62,7 @@ _K1_TUNED = {}
 # pattern kernel: (rows per workgroup, KB of idle LDS per workgroup).  The LDS pad only lowers the number of resident
 # workgroups per CU (4 -> 3): on the devices that dislike large granules that is worth ~2 % (fewer concurrent streams).
 _K1_CANDIDATE_PATTERN = ((1, 0), (1, 8), (2, 0), (4, 0))
-_K1_CANDIDATE_CPW = (1, 2, 4)
+_K1_CANDIDATE_FLAT = ((1, 0), (1, 8), (2, 0), (4, 0))   # flat kernel: (chunks per workgroup, KB of idle LDS)
 
 
 def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
@@ -81,14 +81,11 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
         return
     lib = _lib.load()
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_CPW
+    candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_FLAT
 
     def apply(cand):
-        if pattern:
-            _lib.set_tuning("k1_rows_per_block", cand[0])
-            _lib.set_tuning("k1_lds_pad_kb", cand[1])
-        else:
-            _lib.set_tuning("k1_flat_cpw", cand)
+        _lib.set_tuning("k1_rows_per_block" if pattern else "k1_flat_cpw", cand[0])
+        _lib.set_tuning("k1_lds_pad_kb" if pattern else "k1_flat_lds_pad_kb", cand[1])
 
     def launch(cand):
         apply(cand)
@@ -116,12 +113,12 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
         if timings[c] < best_ms * 0.985:   # prefer the earlier (smaller-granule) candidate unless the gain is clear
             best, best_ms = c, timings[c]
     apply(best)
+    label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
+    ms = {label[c]: timings[c] for c in candidates}
     if pattern:
-        label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
-        _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1],
-                                                 "ms": {label[c]: timings[c] for c in candidates}})
+        _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1], "ms": ms})
     else:
-        _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best, "flat_ms": timings})
+        _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best[0], "flat_lds_pad_kb": best[1], "flat_ms": ms})
 
 
 def set_exact_sqrt(flag: bool) -> None:

@@ -328,7 +328,7 @@ def test_k1_flat_autotune_is_transparent(SB):
     xyz, mask = synth(13, 23, 437)   # 4.39 M pairs
     xg, mg = xyz.cuda(), mask.cuda()
     saved = ops._K1_TUNED.pop(xg.device, None)
-    cpw0 = _lib.get_tuning("k1_flat_cpw")
+    cpw0, fpad0 = _lib.get_tuning("k1_flat_cpw"), _lib.get_tuning("k1_flat_lds_pad_kb")
     try:
         import os
         os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"
@@ -338,11 +338,13 @@ def test_k1_flat_autotune_is_transparent(SB):
         del os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"]
         d1, m1 = ops.pairwise_distance(xg, mg)
         res = ops.k1_autotune_result(xg.device)
-        assert res is not None and res["flat_cpw"] in (1, 2, 4) and set(res["flat_ms"]) == {1, 2, 4}
+        assert res is not None and res["flat_cpw"] in (1, 2, 4) and set(res["flat_ms"]) == {1, "1+8KB", 2, 4}
         assert "rows_per_block" not in res and _lib.get_tuning("k1_flat_cpw") == res["flat_cpw"]
+        assert _lib.get_tuning("k1_flat_lds_pad_kb") == res["flat_lds_pad_kb"]
         assert torch.equal(d0.view(torch.int32), d1.view(torch.int32)) and torch.equal(m0, m1)
     finally:
         _lib.set_tuning("k1_flat_cpw", cpw0)
+        _lib.set_tuning("k1_flat_lds_pad_kb", fpad0)
         ops._K1_TUNED.pop(xg.device, None)
         if saved is not None:
             ops._K1_TUNED[xg.device] = saved
