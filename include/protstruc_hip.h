@@ -69,6 +69,9 @@ int ps_get_tuning(const char* key, int* value);
  *     compact shard:       out_rows = row_end - row_begin, out_row_origin = row_begin
  * `atom_mask` may be NULL (all atoms present); `dist_mask` may be NULL (mask
  * plane not produced); `dist` may be NULL (only the mask plane produced).
+ * Arithmetic: sqrt((dx*dx + dy*dy) + dz*dz) in fp32 without contraction; the square
+ * root is the hardware instruction (exact for 85 % of inputs, 1 ulp off otherwise)
+ * unless ps_set_tuning("k1_exact_sqrt", 1) selects the correctly rounded routine.
  */
 int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask,
                              float* dist, uint8_t* dist_mask,
