@@ -291,6 +291,28 @@ def test_k1_square_root_modes(SB):
             _lib.set_tuning(k, v)
 
 
+def test_k1_misaligned_output_buffers(SB):
+    """Outputs that are only 4-byte (dist) / 1-byte (mask) aligned -- contiguous views into larger buffers -- must
+    still be written correctly and completely (they take the slot-decode / element kernels)."""
+    from protstruc_amd import ops
+    for (B, N, A) in [(2, 37, 15), (2, 32, 15), (1, 40, 5), (2, 7, 15)]:
+        xyz, mask = synth(500 + N + A, B, N, A=A)
+        xg, mg = xyz.cuda(), mask.cuda()
+        ref_d, ref_m = ops.pairwise_distance(xg, mg)
+        numel = ref_d.numel()
+        for off in (1, 2, 3, 5):
+            bd = torch.full((numel + 16,), 777.0, device="cuda")
+            bm = torch.full((numel + 16,), 7, dtype=torch.uint8, device="cuda")
+            d = bd[off:off + numel].view(ref_d.shape)
+            m = bm[off:off + numel].view(torch.bool).view(ref_m.shape)
+            assert d.data_ptr() % 16 != 0 and m.data_ptr() % 16 != 0
+            ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+            assert _same_floats(d, ref_d), (B, N, A, off)
+            assert torch.equal(m, ref_m), (B, N, A, off)
+            assert (bd[:off] == 777.0).all() and (bd[off + numel:] == 777.0).all()
+            assert (bm[:off] == 7).all() and (bm[off + numel:] == 7).all()
+
+
 def test_k1_autotune_is_transparent(SB):
     """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
     from protstruc_amd import _lib, ops
