@@ -313,6 +313,72 @@ def test_k1_misaligned_output_buffers(SB):
             assert (bm[:off] == 7).all() and (bm[off + numel:] == 7).all()
 
 
+def test_k1_capi_argument_validation_streams_and_capture(SB):
+    """The C entry point itself: invalid arguments are rejected before anything is launched (hipErrorInvalidValue = 1),
+    launches on different streams are independent, and the flat / any-A kernels are hipGraph-capturable."""
+    import ctypes
+    from protstruc_amd import _lib, ops
+    lib = _lib.load()
+    xyz, mask = synth(31, 2, 20)
+    xg, mg = xyz.cuda(), mask.cuda().view(torch.uint8)
+    d = torch.full((2, 20, 20, 15, 15), 5.0, device="cuda")
+    m = torch.zeros(2, 20, 20, 15, 15, dtype=torch.uint8, device="cuda")
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    call = lambda *a: lib.ps_pairwise_distance_f32(*a, st)
+    ok = (P(xg), P(mg), P(d), P(m), 2, 20, 15, 0, 20, 20, 0)
+    bad = [
+        (None,) + ok[1:],                                   # no coordinates
+        ok[:2] + (None, None) + ok[4:],                     # neither output plane requested
+        ok[:4] + (-1,) + ok[5:],                            # negative batch
+        ok[:6] + (0,) + ok[7:],                             # A = 0
+        ok[:7] + (-1, 20, 20, 0),                           # row_begin < 0
+        ok[:7] + (5, 21, 20, 0),                            # row_end > N
+        ok[:7] + (7, 5, 20, 0),                             # row_begin > row_end
+        ok[:7] + (5, 10, 4, 5),                             # compact buffer too small for the rows
+        ok[:7] + (5, 10, 20, 6),                            # origin after the first computed row
+    ]
+    for args in bad:
+        assert call(*args) == 1, args
+    torch.cuda.synchronize()
+    assert (d == 5.0).all() and (m == 0).all()             # nothing was written by the rejected calls
+    assert call(*ok) == 0
+    assert call(*(ok[:4] + (0,) + ok[5:])) == 0             # B = 0 is a no-op, not an error
+    ref_d, ref_m = d.clone(), m.clone()
+
+    # two streams, two shapes (flat pattern kernel and any-A kernel), interleaved launches
+    xyz5, mask5 = synth(32, 3, 33, A=5)
+    x5, m5 = xyz5.cuda(), mask5.cuda()
+    want5 = ops.pairwise_distance(x5, m5)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            outs.append(("a", ops.pairwise_distance(xg, mask.cuda())))
+        with torch.cuda.stream(s2):
+            outs.append(("b", ops.pairwise_distance(x5, m5)))
+    torch.cuda.synchronize()
+    for tag, (od, om) in outs:
+        if tag == "a":
+            assert torch.equal(od, ref_d) and torch.equal(om.view(torch.uint8), ref_m)
+        else:
+            assert torch.equal(od, want5[0]) and torch.equal(om, want5[1])
+
+    # graph capture of both kernels; replay after the inputs changed in place
+    g = torch.cuda.CUDAGraph()
+    xa, xb, mgb = xg.clone(), x5.clone(), mask.cuda()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        ga = ops.pairwise_distance(xa, mgb)
+        gb = ops.pairwise_distance(xb, m5)
+    xa.mul_(2.0); xb.add_(1.0)
+    g.replay(); torch.cuda.synchronize()
+    ea = ops.pairwise_distance(xa, mgb); eb = ops.pairwise_distance(xb, m5)
+    assert torch.equal(ga[0], ea[0]) and torch.equal(ga[1], ea[1])
+    assert torch.equal(gb[0], eb[0]) and torch.equal(gb[1], eb[1])
+
+
 def test_k1_autotune_is_transparent(SB):
     """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
     from protstruc_amd import _lib, ops
