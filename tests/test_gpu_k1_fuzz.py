@@ -1,0 +1,74 @@
+"""Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, any-A flat) against its two simple kernels
+(slot-decode for A = 15, element-per-lane otherwise): random shapes, row ranges, compact / in-place outputs, chunk
+counts per workgroup and both square-root modes; outputs sit inside sentinel-filled buffers.  -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_floats(a, b):
+    return torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(7.0).view(torch.int32),
+                                                             b.nan_to_num(7.0).view(torch.int32))
+
+
+def test_k1_fast_kernels_differential_fuzz():
+    assert torch.cuda.is_available()
+    from protstruc_amd import _lib, ops
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_exact_sqrt", "k1_rows_per_block", "k1_jt")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    rng = np.random.default_rng(20261004)
+    SENT = 4321.0
+    try:
+        for trial in range(400):
+            A = int(rng.choice([15, 15, 15, 15, 4, 5, 8, 14, 16, 25, 37, 64]))
+            B = int(rng.integers(1, 5))
+            nmax = {64: 24, 37: 40, 25: 60}.get(A, 200)
+            N = int(rng.integers(16, nmax + 1))
+            g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
+            xyz = torch.randn(B, N, A, 3, generator=g) * float(rng.choice([1.0, 10.0]))
+            mask = torch.rand(B, N, A, generator=g) < float(rng.choice([0.5, 0.9, 1.0]))
+            if trial % 4 == 0:
+                xyz[B - 1, int(rng.integers(0, N))] = float("nan")
+            use_mask = trial % 7 != 0
+            xg, mg = xyz.cuda(), (mask.cuda() if use_mask else None)
+            exact = int(rng.integers(0, 2))
+            _lib.set_tuning("k1_exact_sqrt", exact)
+            # reference path: the simple kernels
+            _lib.set_tuning("k1_variant", 1)
+            _lib.set_tuning("k1_flat", 0)
+            ref_d, ref_m = ops.pairwise_distance(xg, mg)
+            # path under test
+            _lib.set_tuning("k1_variant", 0)
+            _lib.set_tuning("k1_flat", int(rng.choice([1, 1, 2, 3])))
+            _lib.set_tuning("k1_flat_cpw", int(rng.choice([1, 2, 3, 7])))
+            _lib.set_tuning("k1_rows_per_block", int(rng.choice([1, 2, 4, 5])))
+            _lib.set_tuning("k1_jt", int(rng.choice([0, 64, 128])))
+            r0 = int(rng.integers(0, N))
+            r1 = int(rng.integers(r0 + 1, N + 1))
+            if trial % 3 == 0:
+                r0, r1 = 0, N
+            compact = bool(rng.integers(0, 2))
+            rows = (r1 - r0) if compact else N
+            numel = B * rows * N * A * A
+            pad = 32
+            bd = torch.full((numel + 2 * pad,), SENT, device="cuda")
+            bm = torch.full((numel + 2 * pad,), 7, dtype=torch.uint8, device="cuda")
+            d = bd[pad:pad + numel].view(B, rows, N, A, A)
+            m = bm[pad:pad + numel].view(torch.bool).view(B, rows, N, A, A)
+            ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, compact=compact, out_dist=d, out_mask=m)
+            info = (trial, B, N, A, r0, r1, compact, exact, {k: _lib.get_tuning(k) for k in keys})
+            got_d = d if compact else d[:, r0:r1]
+            got_m = m if compact else m[:, r0:r1]
+            assert _same_floats(got_d.contiguous(), ref_d[:, r0:r1].contiguous()), info
+            assert torch.equal(got_m, ref_m[:, r0:r1]), info
+            assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all(), info
+            assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all(), info
+            if not compact:
+                assert (d[:, :r0] == SENT).all() and (d[:, r1:] == SENT).all(), info
+                assert (bm[pad:pad + numel].view(B, N, N, A, A)[:, :r0] == 7).all(), info
+                assert (bm[pad:pad + numel].view(B, N, N, A, A)[:, r1:] == 7).all(), info
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
