@@ -488,6 +488,32 @@ def test_k1_large_n_2048(SB):
     assert torch.equal(cd, d[:, 1280:1536]) and torch.equal(cm, m[:, 1280:1536])
 
 
+@pytest.mark.parametrize("B,N,A", [(2, 2047, 15), (3, 1001, 15), (4, 511, 37), (8, 1023, 4)])
+def test_k1_large_ragged_shapes_properties(SB, B, N, A):
+    """Multi-GB launches of the flat kernels at lengths that are not multiples of anything: sampled blocks against
+    the formula, exact mask checksum per structure, symmetry of a block, no element left unwritten."""
+    from protstruc_amd import ops
+    xyz, mask = synth(40 + N, B, N, A=A)
+    xg, mg = xyz.cuda(), mask.cuda()
+    d = torch.full((B, N, N, A, A), float("nan"), device="cuda")
+    m = torch.zeros(B, N, N, A, A, dtype=torch.bool, device="cuda")
+    ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+    g = torch.Generator().manual_seed(3)
+    bs = torch.randint(0, B, (96,), generator=g)
+    is_ = torch.cat([torch.randint(0, N, (92,), generator=g), torch.tensor([0, N - 1, N - 1, 0])])
+    js = torch.cat([torch.randint(0, N, (92,), generator=g), torch.tensor([0, N - 1, 0, N - 1])])
+    want = torch.norm(xyz[bs, is_][:, :, None, :] - xyz[bs, js][:, None, :, :], dim=-1)
+    assert_close(d[bs.cuda(), is_.cuda(), js.cuda()], want)
+    assert torch.equal(m[bs.cuda(), is_.cuda(), js.cuda()].cpu(), mask[bs, is_][:, :, None] & mask[bs, js][:, None, :])
+    per_struct = mask.reshape(B, -1).sum(1).to(torch.int64)
+    assert torch.equal(torch.stack([torch.count_nonzero(m[b]) for b in range(B)]).cpu(), per_struct * per_struct)
+    assert not torch.isnan(d[B - 1]).any() and not torch.isnan(d[0, N - 1]).any()
+    k = min(N, 200)
+    assert torch.equal(d[B - 1, :k, N - k:], d[B - 1, N - k:, :k].permute(1, 0, 3, 2))
+    del d, m
+    torch.cuda.empty_cache()
+
+
 def test_k1_config4_full_size_properties(SB):
     """BASELINE config 4 at full size on one GPU (B=32, N=2048: 134 M pairs, 151 GB of output -- the largest shape
     BASELINE names): sampled blocks against the oracle's formula, exact mask checksum per structure, symmetry."""
