@@ -140,6 +140,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowshard", action="store_true")
+    ap.add_argument("--shop-allocations", type=int, default=0,
+                    help="opt-in experiment: pick the fastest of K output allocations (reported in config); default off")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
     args = ap.parse_args()
 
@@ -180,8 +182,14 @@ def main():
     _lib.load()  # fails loudly if the HIP library is missing
     xyz_cpu, mask_cpu = synth(seed=rank)  # rank 0 / N=1: seed 0 as in SURVEY 8(d)
     xyz, mask = xyz_cpu.to(dev), mask_cpu.to(dev)
-    out_d = torch.empty(B, N_RES, N_RES, N_ATOM, N_ATOM, device=dev)
-    out_m = torch.empty(B, N_RES, N_RES, N_ATOM, N_ATOM, dtype=torch.bool, device=dev)
+    shop_report = None
+    if args.shop_allocations > 1:
+        # opt-in, OFF by default: keep the fastest of K output allocations (ops.allocate_fast_outputs; DESIGN.md
+        # section 4, "fast and slow allocations").  The default run takes whatever torch.empty returns.
+        out_d, out_m, shop_report = ops.allocate_fast_outputs(xyz, mask, candidates=args.shop_allocations)
+    else:
+        out_d = torch.empty(B, N_RES, N_RES, N_ATOM, N_ATOM, device=dev)
+        out_m = torch.empty(B, N_RES, N_RES, N_ATOM, N_ATOM, dtype=torch.bool, device=dev)
 
     def step():
         ops.pairwise_distance(xyz, mask, out_dist=out_d, out_mask=out_m)
@@ -224,7 +232,9 @@ def main():
                                                                  "k1_xcd_remap", "k1_exact_sqrt", "k1_lds_pad_kb")},
                    "k1_sqrt": ("correctly rounded" if _lib.get_tuning("k1_exact_sqrt")
                                else "hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise; parity gate 1e-5 abs)"),
-                   "k1_autotune": ops.k1_autotune_result(dev)},
+                   "k1_autotune": ops.k1_autotune_result(dev),
+                   "output_allocation": ("torch.empty (default)" if shop_report is None
+                                         else {"best_of": args.shop_allocations, **shop_report})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                      "kernel": "k1_pairdist_a15_pat", "kernel_ms": kernel_ms_max,

@@ -140,6 +140,47 @@ def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tens
     return k1_autotune_result(xyz.device)
 
 
+def allocate_fast_outputs(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, candidates: int = 4):
+    """Output buffers for ``pairwise_distance(..., out_dist=, out_mask=)``, chosen as the fastest of ``candidates``
+    fresh allocations.
+
+    Why this exists: on MI355X the rate at which K1's store stream is absorbed depends on which physical memory the
+    output landed in -- 6.0 to 7.1 TB/s for the same kernel in one process ("fast and slow
+    allocations") -- and a caller who keeps its output buffers for many steps inherits that luck for the whole run.
+    This helper allocates the (dist, mask) pair ``candidates`` times (all held at once: candidates x 1125 B per
+    residue pair), times two launches on each, returns the fastest pair and releases the others.
+    Returns ``(dist, mask, report)``; results written into the buffers are the same whichever pair is chosen."""
+    xyz = _f32c(xyz, "xyz")
+    B, N, A = xyz.shape[:3]
+    shape = (B, N, N, A, A)
+    pairs = []
+    with torch.cuda.device(xyz.device):
+        for _ in range(max(1, int(candidates))):
+            pairs.append((torch.empty(shape, dtype=torch.float32, device=xyz.device),
+                          torch.empty(shape, dtype=torch.bool, device=xyz.device)))
+        pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])   # autotune + warm-up
+        t_end = time.perf_counter() + 0.12
+        while time.perf_counter() < t_end:
+            pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])
+            torch.cuda.current_stream(xyz.device).synchronize()
+        ms = [float("inf")] * len(pairs)
+        for _ in range(2):
+            for k, (d, m) in enumerate(pairs):
+                pairwise_distance(xyz, atom_mask, out_dist=d, out_mask=m)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                pairwise_distance(xyz, atom_mask, out_dist=d, out_mask=m)
+                pairwise_distance(xyz, atom_mask, out_dist=d, out_mask=m)
+                e1.record()
+                e1.synchronize()
+                ms[k] = min(ms[k], e0.elapsed_time(e1) / 2)
+        best = min(range(len(pairs)), key=lambda k: ms[k])
+        d, m = pairs[best]
+        del pairs
+        torch.cuda.empty_cache()
+    return d, m, {"ms_per_candidate": ms, "chosen": best}
+
+
 def k1_autotune_result(device=None):
     """What the one-time K1 autotune chose on ``device`` (None if it has not run)."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)

@@ -379,6 +379,20 @@ def test_k1_capi_argument_validation_streams_and_capture(SB):
     assert torch.equal(gb[0], eb[0]) and torch.equal(gb[1], eb[1])
 
 
+def test_k1_allocate_fast_outputs(SB):
+    """The allocation-shopping helper returns usable buffers and a report; results do not depend on the choice."""
+    from protstruc_amd import ops
+    xyz, mask = synth(51, 4, 128)
+    xg, mg = xyz.cuda(), mask.cuda()
+    d, m, rep = ops.allocate_fast_outputs(xg, mg, candidates=3)
+    assert d.shape == (4, 128, 128, 15, 15) and m.shape == d.shape and m.dtype == torch.bool
+    assert len(rep["ms_per_candidate"]) == 3 and 0 <= rep["chosen"] < 3
+    assert rep["ms_per_candidate"][rep["chosen"]] == min(rep["ms_per_candidate"])
+    ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+    rd, rm = ops.pairwise_distance(xg, mg)
+    assert torch.equal(d, rd) and torch.equal(m, rm)
+
+
 def test_k1_autotune_is_transparent(SB):
     """The one-time per-device autotune changes speed only: results are bit-identical before and after."""
     from protstruc_amd import _lib, ops
