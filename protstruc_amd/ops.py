@@ -44,6 +44,35 @@ def _u8c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
     return (t != 0).contiguous().view(torch.uint8)
 
 
+def _check_rng_state(rng_state: Optional[torch.Tensor], device: torch.device) -> None:
+    """The kernels atomically update words 1, 2 and 16 + 16 r (r < 32) of ``rng_state`` on the device: anything but a
+    contiguous int64 tensor of RNG_STATE_WORDS words on the coordinates' own GPU would be an out-of-bounds (or
+    host-pointer) access, so it is refused before the launch."""
+    if rng_state is None:
+        return
+    if not isinstance(rng_state, torch.Tensor) or rng_state.dtype != torch.int64:
+        raise ValueError(f"rng_state must be an int64 tensor of {RNG_STATE_WORDS} words")
+    if not rng_state.is_cuda or rng_state.device != device:
+        raise ValueError(f"rng_state lives on {rng_state.device}, the coordinates on {device}")
+    if rng_state.ndim != 1 or rng_state.numel() < RNG_STATE_WORDS or not rng_state.is_contiguous():
+        raise ValueError(f"rng_state must be a contiguous 1-D int64 tensor of {RNG_STATE_WORDS} words "
+                         f"(got shape {tuple(rng_state.shape)})")
+
+
+def _same_device(ref: torch.Tensor, **tensors) -> None:
+    for name, t in tensors.items():
+        if t is not None and t.device != ref.device:
+            raise ValueError(f"`{name}` lives on {t.device}, the coordinates on {ref.device}")
+
+
+def _check_out(t: Optional[torch.Tensor], shape, name: str, device: torch.device) -> None:
+    if t is None:
+        return
+    if (not isinstance(t, torch.Tensor) or tuple(t.shape) != tuple(shape) or t.dtype != torch.float32
+            or not t.is_contiguous() or t.device != device):
+        raise ValueError(f"{name} must be a contiguous float32 tensor of shape {tuple(shape)} on {device}")
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -336,8 +365,8 @@ def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Te
             raise ValueError("noise must have the shape of xyz")
     elif rng_state is None:
         raise ValueError("either rng_state or noise is required")
-    if rng_state is not None and (rng_state.numel() < RNG_STATE_WORDS or rng_state.dtype != torch.int64):
-        raise ValueError(f"rng_state must be an int64 tensor of {RNG_STATE_WORDS} words")
+    _check_rng_state(rng_state, xyz.device)
+    _same_device(xyz, beta=beta, noise=noise)
     with torch.cuda.device(xyz.device):
         rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
     _lib.check(rc, "ps_diffuse_f32")
@@ -357,9 +386,18 @@ def diffuse_frames_(xyz: torch.Tensor, beta: torch.Tensor, a1: int, a2: int, a3:
         raise ValueError(f"beta must have shape ({B},), got {tuple(beta.shape)}")
     if noise is not None:
         noise = _f32c(noise, "noise")
+        if noise.shape != xyz.shape:
+            raise ValueError("noise must have the shape of xyz")
     elif rng_state is None:
         raise ValueError("either rng_state or noise is required")
+    _check_rng_state(rng_state, xyz.device)
+    _same_device(xyz, beta=beta, noise=noise)
+    for slot in (a1, a2, a3, t_atom):
+        if not 0 <= int(slot) < A:
+            raise ValueError(f"atom slot {slot} outside [0, {A})")
     dev = xyz.device
+    _check_out(out_rot, (B, N, 3, 3), "out_rot", dev)
+    _check_out(out_trans, (B, N, 3), "out_trans", dev)
     with torch.cuda.device(dev):
         rot = out_rot if out_rot is not None else torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev)
         trans = out_trans if out_trans is not None else torch.empty(B, N, 3, dtype=torch.float32, device=dev)
@@ -371,9 +409,11 @@ def diffuse_frames_(xyz: torch.Tensor, beta: torch.Tensor, a1: int, a2: int, a3:
 
 def diffusion_trajectory_(xyz: torch.Tensor, betas: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int,
                           rng_state: torch.Tensor, want_rot: bool = True, want_trans: bool = True,
-                          want_xyz: bool = False):
+                          want_xyz: bool = False, *, out_rot: Optional[torch.Tensor] = None,
+                          out_trans: Optional[torch.Tensor] = None, out_xyz: Optional[torch.Tensor] = None):
     """K55: T diffusion steps in one launch, coordinates resident in LDS.  ``betas``: (T, B).
-    Returns (rot (T,B,N,3,3) | None, trans (T,B,N,3) | None, xyz_traj (T,B,N,A,3) | None); ``xyz`` ends as step T."""
+    Returns (rot (T,B,N,3,3) | None, trans (T,B,N,3) | None, xyz_traj (T,B,N,A,3) | None); ``xyz`` ends as step T.
+    ``out_rot`` / ``out_trans`` / ``out_xyz`` supply caller-owned output buffers (and imply the matching ``want_``)."""
     _require_device(xyz, "xyz")
     if xyz.dtype != torch.float32 or not xyz.is_contiguous():
         raise ValueError("diffusion_trajectory_ needs a contiguous float32 xyz (it is updated in place)")
@@ -382,13 +422,24 @@ def diffusion_trajectory_(xyz: torch.Tensor, betas: torch.Tensor, a1: int, a2: i
     if betas.ndim != 2 or betas.shape[1] != B:
         raise ValueError(f"betas must have shape (T, {B}), got {tuple(betas.shape)}")
     T = betas.shape[0]
-    if rng_state is None or rng_state.numel() < RNG_STATE_WORDS or rng_state.dtype != torch.int64:
+    if rng_state is None:
         raise ValueError(f"rng_state must be an int64 tensor of {RNG_STATE_WORDS} words")
+    _check_rng_state(rng_state, xyz.device)
+    for slot in (a1, a2, a3, t_atom):
+        if not 0 <= int(slot) < A:
+            raise ValueError(f"atom slot {slot} outside [0, {A})")
     dev = xyz.device
+    _same_device(xyz, betas=betas)
+    _check_out(out_rot, (T, B, N, 3, 3), "out_rot", dev)
+    _check_out(out_trans, (T, B, N, 3), "out_trans", dev)
+    _check_out(out_xyz, (T, B, N, A, 3), "out_xyz", dev)
     with torch.cuda.device(dev):
-        rot = torch.empty(T, B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None
-        trans = torch.empty(T, B, N, 3, dtype=torch.float32, device=dev) if want_trans else None
-        traj = torch.empty(T, B, N, A, 3, dtype=torch.float32, device=dev) if want_xyz else None
+        rot = out_rot if out_rot is not None else (
+            torch.empty(T, B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None)
+        trans = out_trans if out_trans is not None else (
+            torch.empty(T, B, N, 3, dtype=torch.float32, device=dev) if want_trans else None)
+        traj = out_xyz if out_xyz is not None else (
+            torch.empty(T, B, N, A, 3, dtype=torch.float32, device=dev) if want_xyz else None)
         rc = _lib.load().ps_diffusion_trajectory_f32(_ptr(xyz), _ptr(betas), T, B, N, A, _ptr(rng_state), _ptr(rot),
                                                      _ptr(trans), _ptr(traj), int(a1), int(a2), int(a3), int(t_atom),
                                                      _stream(xyz))

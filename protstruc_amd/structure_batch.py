@@ -416,14 +416,16 @@ class StructureBatch:
 
     def diffuse_trajectory(self, betas: torch.FloatTensor, a1: str = "N", a2: str = "CA", a3: str = "C",
                            atom: str = "CA", want_orientations: bool = True, want_translations: bool = True,
-                           want_xyz: bool = False):
+                           want_xyz: bool = False, out_orientations: Optional[torch.Tensor] = None,
+                           out_translations: Optional[torch.Tensor] = None, out_xyz: Optional[torch.Tensor] = None):
         """The diffusion loop ``for t: diffuse_xyz(betas[t]); backbone_orientations()`` as ONE launch.
 
         ``betas`` has shape (T, B).  The coordinates stay in on-chip LDS between steps; only the
         per-step outputs that are asked for are written: orientations (T,B,N,3,3), translations
         (T,B,N,3), coordinates (T,B,N,A,3).  The result is bit-identical to T calls of
-        ``diffuse_xyz_and_frames`` and ``get_xyz()`` ends at step T."""
+        ``diffuse_xyz_and_frames`` and ``get_xyz()`` ends at step T.  ``out_*`` supply caller-owned buffers."""
         if self._rng_state is None:
             self.manual_seed(torch.initial_seed())
         return ops.diffusion_trajectory_(self.xyz, betas.to(self.device), ATOM[a1], ATOM[a2], ATOM[a3], ATOM[atom],
-                                         self._rng_state, want_orientations, want_translations, want_xyz)
+                                         self._rng_state, want_orientations, want_translations, want_xyz,
+                                         out_rot=out_orientations, out_trans=out_translations, out_xyz=out_xyz)

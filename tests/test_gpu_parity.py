@@ -707,6 +707,111 @@ def test_config5_shape_diffusion_loop(SB):
     assert mean.abs().max() < 0.05
 
 
+def cosine_betas(T, s=8e-3, beta_max=0.999):
+    """Variance schedule of the reference's diffusion tutorial (docs/tutorials/diffusing_xyz_coordinates.ipynb,
+    cell 2; loop shape README.md:120-150): alpha_bar_t = cos^2((t/T + s)/(1 + s) * pi/2) / alpha_bar_0,
+    beta_t = clip(1 - alpha_bar_t / alpha_bar_{t-1}, 1e-5, beta_max), beta_0 = 0; the loop uses beta[0..T-1]."""
+    t = torch.arange(T + 1)
+    f = torch.cos((t / T + s) / (1 + s) * torch.pi / 2.0).square()
+    abar = f / f[0]
+    beta = torch.cat([torch.zeros(1), (1 - abar[1:] / abar[:-1]).clamp(min=1e-5, max=beta_max)])
+    return beta[:T].float()
+
+
+def test_config5_full_T300_graph(SB):
+    """BASELINE config 5 at its stated size: B=256, N_res=384, cosine schedule T=300, standardize once, then
+    (a) the loop diffuse_xyz + backbone_orientations captured in ONE hipGraph and replayed, against
+    (b) the LDS-resident trajectory kernel without and with the per-step coordinates (5.3 GB, > 2^32 bytes).
+    Reference: protstruc.py:696-734 (standardize), :864-878 (diffuse_xyz), :543-571 (frames); README.md:120-150."""
+    B, N, A, T = 256, 384, 15, 300
+    xyz, mask = synth(55, B, N, scale=8.0)
+    betas = cosine_betas(T)
+    assert betas[0] == 0 and betas[-1] > 0.5 and betas.shape == (T,)
+    betas_TB = betas[:, None].expand(T, B).contiguous().cuda()
+    checks = (0, 149, 299)  # steps 1, 150, 300
+
+    a = SB.from_xyz(xyz.clone(), mask).manual_seed(1234)
+    a.standardize()
+    ref_std, mu, sd = O.standardize(xyz[:8], mask[:8])
+    assert_close(a.mu[:8], mu, tol=3e-5)
+    assert_close(a.std[:8], sd, tol=3e-5)
+    assert_close(a.get_xyz()[:8], ref_std, tol=3e-5)
+    xyz0 = a.get_xyz().clone()          # standardized start, shared by all three runs
+    seed_state = a._rng_state.clone()
+
+    # ---- (a) the whole loop in one captured graph --------------------------------------------------------------
+    beta_dev = [betas_TB[t] for t in range(T)]   # (B,) device views: nothing is copied at launch time
+    a.diffuse_xyz(beta_dev[1]); a.backbone_orientations()    # warm-up outside capture (library + allocator)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    rots_a = []
+    with torch.cuda.graph(graph):
+        for t in range(T):
+            a.diffuse_xyz(beta_dev[t])
+            rots_a.append(a.backbone_orientations())
+    a.get_xyz().copy_(xyz0)              # undo the warm-up: same start and same draw counter as (b)
+    a._rng_state.copy_(seed_state)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(a._rng_state[1]) == T and not a._rng_state[2:].any(), "draw counter must advance by T, tickets back to 0"
+    final_a = a.get_xyz().clone()
+    keep_a = {t: rots_a[t].clone() for t in checks}
+    # a second replay continues the noise stream (fresh noise, not a repeat)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert int(a._rng_state[1]) == 2 * T and not torch.equal(a.get_xyz(), final_a)
+    del graph, rots_a
+
+    # ---- (b1) trajectory kernel, frames only ---------------------------------------------------------------------
+    b = SB.from_xyz(xyz0.clone(), mask).manual_seed(1234)
+    rot_b, trans_b, none_xyz = b.diffuse_trajectory(betas_TB)
+    torch.cuda.synchronize()
+    assert none_xyz is None and rot_b.shape == (T, B, N, 3, 3) and trans_b.shape == (T, B, N, 3)
+    assert int(b._rng_state[1]) == T
+    for t in checks:
+        assert torch.equal(rot_b[t], keep_a[t]), f"step {t + 1}: trajectory kernel != captured loop"
+    assert torch.equal(b.get_xyz(), final_a)
+    assert torch.equal(trans_b[T - 1], final_a[:, :, 1])
+
+    # ---- (b2) the same with the per-step coordinates into a NaN-prefilled 5.3 GB buffer -----------------------
+    c = SB.from_xyz(xyz0.clone(), mask).manual_seed(1234)
+    traj = torch.full((T, B, N, A, 3), float("nan"), device="cuda")
+    assert traj.numel() * 4 > 2 ** 32
+    rot_c = torch.full((T, B, N, 3, 3), float("nan"), device="cuda")
+    rot_c2, trans_c, traj2 = c.diffuse_trajectory(betas_TB, want_translations=False, out_orientations=rot_c, out_xyz=traj)
+    torch.cuda.synchronize()
+    assert rot_c2 is rot_c and traj2 is traj and trans_c is None
+    assert not torch.isnan(traj).any(), "unwritten part of xyz_traj"
+    assert not torch.isnan(rot_c[:, :8]).any()
+    assert torch.equal(traj[T - 1], c.get_xyz()) and torch.equal(c.get_xyz(), final_a)
+    assert torch.equal(traj[0], xyz0), "beta_0 = 0 leaves the coordinates untouched (sqrt(0) * eps = 0)"
+    for t in checks:
+        assert torch.equal(rot_c[t], keep_a[t])
+        assert torch.equal(trans_b[t], traj[t][:, :, 1])
+    # consecutive steps obey the update rule with SOME unit-variance noise: (x_t - sqrt(1-b) x_{t-1}) / sqrt(b)
+    t = 150
+    eps = (traj[t] - (1 - betas[t]).sqrt().item() * traj[t - 1]) / betas[t].sqrt().item()
+    assert abs(eps.mean().item()) < 5e-3 and abs(eps.var().item() - 1.0) < 5e-3
+
+    # ---- frames of 8 sampled structures at step 300 against the oracle on the final coordinates -----------------
+    idx = torch.tensor([0, 31, 64, 100, 127, 200, 254, 255])
+    fin = traj[T - 1][idx.cuda()].cpu()
+    want = O.backbone_orientations(fin)
+    truth = O.backbone_orientations(fin.double())
+    got = rot_c[T - 1][idx.cuda()]
+    assert_close(got, want, bad_frac=1e-3)
+    e_got = (got.cpu().double() - truth).abs().max().item()
+    e_ref = (want.double() - truth).abs().max().item()
+    assert e_got <= max(4 * e_ref, 2e-5)
+    # ---- after 300 steps alpha_bar ~ 0: every coordinate is N(0,1); masked per-structure statistics ~ (0, 1) ---
+    z = traj[T - 1]
+    w = mask.cuda().unsqueeze(-1).float()
+    cnt = w.sum((1, 2))
+    mean = (z * w).sum((1, 2)) / cnt
+    var = (((z - mean[:, None, None]) ** 2) * w).sum((1, 2)) / cnt
+    assert mean.abs().max().item() < 0.08 and (var - 1).abs().max().item() < 0.12
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)
@@ -863,6 +968,52 @@ def test_k5_sampler_statistics(SB):
     sb3.diffuse_xyz(betas)
     v = sb3.get_xyz().reshape(B, -1).var(dim=1).cpu()
     assert torch.allclose(v, betas, rtol=0.05)
+
+
+def test_k5_argument_validation_before_launch(SB):
+    """Everything the sampler kernels dereference is validated on the host: a short / CPU / mistyped rng_state, a
+    mis-shaped noise tensor or output buffer raises ValueError before anything is launched."""
+    from protstruc_amd import ops
+    B, N, A = 2, 8, 15
+    xyz = torch.randn(B, N, A, 3, device="cuda")
+    beta = torch.full((B,), 0.1, device="cuda")
+    betas = beta[None].expand(3, B).contiguous()
+    good = torch.zeros(ops.RNG_STATE_WORDS, dtype=torch.int64, device="cuda")
+    before = xyz.clone()
+    bad_states = [
+        torch.zeros(2, dtype=torch.int64, device="cuda"),                      # the [seed, offset] pair alone
+        torch.zeros(ops.RNG_STATE_WORDS, dtype=torch.int64),                   # host memory
+        torch.zeros(ops.RNG_STATE_WORDS, dtype=torch.int32, device="cuda"),    # wrong word size
+        torch.zeros(2 * ops.RNG_STATE_WORDS, dtype=torch.int64, device="cuda")[::2],   # strided
+    ]
+    for st in bad_states:
+        with pytest.raises(ValueError):
+            ops.diffuse_(xyz, beta, st)
+        with pytest.raises(ValueError):
+            ops.diffuse_frames_(xyz, beta, 0, 1, 2, 1, st)
+        with pytest.raises(ValueError):
+            ops.diffusion_trajectory_(xyz, betas, 0, 1, 2, 1, st)
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta, 0, 1, 2, 1, None, noise=torch.zeros(B, N, A - 1, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta[:1], 0, 1, 2, 1, good)
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta, 0, 1, A, 1, good)                        # atom slot out of range
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta, 0, 1, 2, 1, good, out_rot=torch.empty(B, N, 9, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta, 0, 1, 2, 1, good, out_trans=torch.empty(B, N, 3, dtype=torch.float64, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.diffuse_frames_(xyz, beta, 0, 1, 2, 1, good, out_rot=torch.empty(B, N, 3, 3))   # host buffer
+    with pytest.raises(ValueError):
+        ops.diffusion_trajectory_(xyz, betas, 0, 1, 2, 1, good, out_xyz=torch.empty(2, B, N, A, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        ops.diffuse_(xyz, beta.cpu().to("cuda")[:1], good)
+    torch.cuda.synchronize()
+    assert torch.equal(xyz, before) and not good.any(), "a refused call must not have launched anything"
+    ops.diffuse_(xyz, beta, good)                                             # and the good state still works
+    torch.cuda.synchronize()
+    assert int(good[1]) == 1 and not good[2:].any() and not torch.equal(xyz, before)
 
 
 def test_k5_graph_capture_replays_fresh_noise(SB):
