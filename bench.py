@@ -13,16 +13,22 @@ outputs are resident in HBM before the timed region.
 * N = 1: the headline workload on one GPU.
 * N > 1: weak scaling -- every rank owns its own B=64 batch (structures are
   independent; no data-path collective); value = all pairs of all ranks divided
-  by the slowest rank's time.  After the timed region (and guarded by a
-  watchdog) the residue-sharded variant of the north star -- rows [r*N/P,
-  (r+1)*N/P) per rank into one full-size buffer, then an RCCL all-gather over
-  xGMI -- is timed separately and reported under "rowshard_allgather".
+  by the slowest rank's time.  After the timed region (guarded by a watchdog that
+  makes a stall a NON-ZERO exit) the residue-sharded form of the north star --
+  BASELINE config 4 at full size, B=32, N_res=2048: rows [r*N/P, (r+1)*N/P) per
+  rank into one full-size buffer, then the RCCL all-gather over xGMI -- is timed
+  with HIP events and reported under "rowshard_allgather".
+
+After the timed region the buffers that were just timed are CHECKED (sampled
+blocks against the fp32 formula, exact mask checksum per structure, symmetry of
+one structure); a failed check prints no result line and exits non-zero.
 
 ``roofline.achieved`` = algorithmic bytes per launch (1125 B per residue pair:
 225 fp32 distances + 225 mask bytes) / mean launch duration
 measured with HIP events on the launch stream inside the timed region.
 ``cpu_baseline`` (N = 1 only) times the CPU oracle -- the same ATen op sequence
-as the reference -- on a bounded sample of the same workload on the host cores.
+as the reference -- on a bounded sample of the same workload on the host cores,
+at the default thread count and at one thread.
 """
 import argparse
 import json
@@ -39,6 +45,8 @@ sys.path.insert(0, ROOT)
 B, N_RES, N_ATOM = 64, 512, 15
 BYTES_PER_PAIR = N_ATOM * N_ATOM * 4 + N_ATOM * N_ATOM  # 900 + 225
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip table)
+XGMI_LINK_GBPS = 153.0  # per xGMI link and direction (MI355X_MICROARCH.md); a GPU has 7 links
+C4_B, C4_N = 32, 2048   # BASELINE config 4
 
 
 def synth(seed, b=B, n=N_RES, a=N_ATOM):
@@ -50,34 +58,65 @@ def synth(seed, b=B, n=N_RES, a=N_ATOM):
     return xyz, mask
 
 
-def cpu_baseline(xyz, mask, budget_s=12.0):
-    """Oracle (PyTorch-CPU restatement of reference protstruc.py:477-483) on a bounded sample."""
+def host_cpu_info():
+    """Model name, logical CPUs, physical cores and sockets from /proc/cpuinfo (no external tools)."""
+    model, cores, sockets = "?", set(), set()
+    try:
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "?":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                    sockets.add(phys)
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    return {"host_cpu": model, "host_logical_cpus": os.cpu_count(), "host_physical_cores": len(cores) or None,
+            "host_sockets": len(sockets) or None}
+
+
+def _time_oracle(xyz, mask, budget_s, min_structs):
     from oracle import protstruc_oracle as O
 
-    threads = torch.get_num_threads()
-    O.pairwise_distance_matrix(xyz[:1], mask[:1])  # warm-up (allocator, threads)
     done, t0 = 0, time.perf_counter()
     while done < xyz.shape[0]:
         O.pairwise_distance_matrix(xyz[done:done + 1], mask[done:done + 1])
         done += 1
-        if time.perf_counter() - t0 > budget_s and done >= 2:
+        if time.perf_counter() - t0 > budget_s and done >= min_structs:
             break
-    dt = time.perf_counter() - t0
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(xyz, mask, budget_s=10.0, budget_1t_s=6.0):
+    """Oracle (PyTorch-CPU restatement of reference protstruc.py:477-483) on a bounded sample of the same workload:
+    one structure per call (the monolithic call needs ~64 GB of temporaries), at torch's default thread count and
+    at ONE thread (BASELINE.md section 4 asks for both)."""
+    from oracle import protstruc_oracle as O
+
     n = xyz.shape[1]
-    model = "?"
-    try:
-        with open("/proc/cpuinfo") as f:
-            for line in f:
-                if line.startswith("model name"):
-                    model = line.split(":", 1)[1].strip()
-                    break
-    except OSError:
-        pass
-    return {
+    threads = torch.get_num_threads()
+    O.pairwise_distance_matrix(xyz[:1], mask[:1])  # warm-up (allocator, thread pool)
+    done, dt = _time_oracle(xyz, mask, budget_s, 2)
+    out = {
         "value": done * n * n / dt, "unit": "residue-pairs/s", "cores": threads, "kind": "port",
         "sample": f"first {done} of {xyz.shape[0]} structures (N_res={n}), one structure per call, {dt:.1f} s",
-        "host_cpu": model, "host_logical_cpus": os.cpu_count(),
     }
+    try:
+        torch.set_num_threads(1)
+        done1, dt1 = _time_oracle(xyz, mask, budget_1t_s, 1)
+        out["single_thread"] = {"value": done1 * n * n / dt1, "unit": "residue-pairs/s", "cores": 1,
+                                "sample": f"first {done1} of {xyz.shape[0]} structures, {dt1:.1f} s"}
+    finally:
+        torch.set_num_threads(threads)
+    out.update(host_cpu_info())
+    return out
 
 
 def load_traffic():
@@ -87,44 +126,105 @@ def load_traffic():
         with open(p) as f:
             t = json.load(f)
         if t.get("B") == B and t.get("N_res") == N_RES:
-            return t.get("hbm_bytes_per_launch")
+            return t.get("hbm_bytes_per_launch"), ("profiles/k1_traffic.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of "
+                                                    "this command, committed; NOT re-measured inside this run")
     except (OSError, ValueError):
         pass
-    return None
+    return None, None
 
 
-def rowshard_allgather(dev, rank, world, max_over_ranks, steps=3):
-    """North-star config 4 in miniature: residue-sharded K1 into a full-size buffer + RCCL all-gather."""
+def check_outputs(xyz, mask, out_d, out_m, n_blocks=64, seed=7):
+    """Verify, OUTSIDE the timed region, the buffers the timed launches wrote.  Returns a list of failures."""
+    dev = out_d.device
+    b_, n_ = xyz.shape[:2]
+    fails = []
+    g = torch.Generator().manual_seed(seed)
+    bs = torch.randint(0, b_, (n_blocks,), generator=g).to(dev)
+    i_s = torch.randint(0, n_, (n_blocks,), generator=g).to(dev)
+    js = torch.randint(0, n_, (n_blocks,), generator=g).to(dev)
+    got = out_d[bs, i_s, js]                                                    # (n_blocks, A, A)
+    diff = xyz[bs, i_s][:, :, None, :] - xyz[bs, js][:, None, :, :]
+    want = (diff * diff).sum(-1).sqrt()                                         # the fp32 formula, on the device
+    err = (got - want).abs().max().item()
+    if not err <= 1e-5:
+        fails.append(f"sampled blocks: max |d - formula| = {err:.3e} > 1e-5")
+    want_m = mask[bs, i_s][:, :, None] & mask[bs, js][:, None, :]
+    if not torch.equal(out_m[bs, i_s, js], want_m):
+        fails.append("sampled mask blocks differ")
+    # exact checksum of the whole mask plane, per structure: sum = (number of present atoms)^2
+    count = mask.sum((1, 2), dtype=torch.int64)
+    got_sum = out_m.view(torch.uint8).sum((1, 2, 3, 4), dtype=torch.int64)
+    if not torch.equal(got_sum, count * count):
+        fails.append("mask checksum per structure differs from (present atoms)^2")
+    # symmetry of one whole structure: d[i,j,a,c] == d[j,i,c,a] bit for bit
+    bsym = int(bs[0])
+    if not torch.equal(out_d[bsym], out_d[bsym].permute(1, 0, 3, 2)):
+        fails.append(f"structure {bsym} is not symmetric")
+    if torch.isnan(out_d[bsym]).any():
+        fails.append(f"structure {bsym} holds NaN")
+    return fails
+
+
+def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, steps=2):
+    """BASELINE config 4: residue-sharded K1 into a full-size buffer + all-gather (native RCCL and torch paths),
+    each part timed with HIP events on the launch stream; max over ranks."""
     import torch.distributed as dist
-    from protstruc_amd.distributed import pairwise_distance_matrix_sharded
+    from protstruc_amd import distributed as D
+    from protstruc_amd import ops
 
-    b, n = 8, 2048
+    b, n = (C4_B, C4_N) if not shared_gpu else (2, C4_N)   # ranks sharing one card (gloo rehearsal) cannot hold 151 GB each
     xyz, mask = synth(1234, b, n)  # same seed on every rank: inputs are replicated, only outputs are sharded
     xyz, mask = xyz.to(dev), mask.to(dev)
     out_d = torch.empty(b, n, n, N_ATOM, N_ATOM, device=dev)
     out_m = torch.empty(b, n, n, N_ATOM, N_ATOM, dtype=torch.bool, device=dev)
-    res = {}
-    for gather in (False, "recompute", True):
-        for _ in range(1):
-            pairwise_distance_matrix_sharded(xyz, mask, gather=gather, out_dist=out_d, out_mask=out_m)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            pairwise_distance_matrix_sharded(xyz, mask, gather=gather, out_dist=out_d, out_mask=out_m)
-        torch.cuda.synchronize(dev)
-        dist.barrier()
-        dt = max_over_ranks([(time.perf_counter() - t0) / steps])[0]
-        key = {False: "kernel_only_ms", True: "kernel_plus_allgather_ms", "recompute": "full_matrix_recomputed_per_rank_ms"}
-        res[key[gather]] = dt * 1e3
+    lo, hi = D.shard_rows(n, rank, world)
     pairs = b * n * n
-    res.update({
-        "workload": f"B={b}, N_res={n}, rows sharded over {world} ranks",
-        "pairs_per_s_kernel_only": pairs / (res["kernel_only_ms"] * 1e-3),
-        "pairs_per_s_with_allgather": pairs / (res["kernel_plus_allgather_ms"] * 1e-3),
-        "allgather_GBps_per_rank_ingress": pairs * BYTES_PER_PAIR * (world - 1) / world
-        / max((res["kernel_plus_allgather_ms"] - res["kernel_only_ms"]) * 1e-3, 1e-9) / 1e9,
-    })
+    total_bytes = pairs * BYTES_PER_PAIR
+
+    def timed(fn, reps):
+        fn()                                   # warm-up (autotune of the shard shape, communicator creation)
+        torch.cuda.synchronize(dev)
+        dist.barrier()
+        ms = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+            dist.barrier()
+        return max_over_ranks([sum(ms) / len(ms)])[0]
+
+    res = {"workload": f"B={b}, N_res={n}, N_atom={N_ATOM}; rows sharded over {world} ranks ({hi - lo} rows on rank {rank})",
+           "backend": backend, "algorithmic_bytes_total": total_bytes}
+    kernel = lambda: ops.pairwise_distance(xyz, mask, row_begin=lo, row_end=hi, out_dist=out_d, out_mask=out_m)
+    res["kernel_only_ms"] = timed(kernel, steps + 1)
+    res["kernel_only_pairs_per_s"] = pairs / (res["kernel_only_ms"] * 1e-3)
+    res["kernel_only_GBps_per_rank"] = total_bytes / world / (res["kernel_only_ms"] * 1e-3) / 1e9
+    impls = ("native", "torch") if backend == "nccl" else ("torch",)
+    for impl in impls:
+        def gather_only(impl=impl):
+            D.allgather_rows(out_d, impl=impl)
+            D.allgather_rows(out_m, impl=impl)
+        key = f"allgather_{impl}"
+        try:
+            res[key + "_ms"] = timed(gather_only, steps)
+            ingress = total_bytes * (world - 1) / world
+            res[key + "_ingress_GBps_per_rank"] = ingress / (res[key + "_ms"] * 1e-3) / 1e9
+        except Exception as exc:  # noqa: BLE001 -- keep the other variant's numbers; surfaced at top level by the caller
+            res[key + "_error"] = f"{type(exc).__name__}: {exc}"
+    res["xgmi_ingress_bound_GBps_per_rank"] = XGMI_LINK_GBPS * min(world - 1, 7)
+    best = min((res[k] for k in ("allgather_native_ms", "allgather_torch_ms") if k in res), default=None)
+    e2e = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather=True, out_dist=out_d, out_mask=out_m)
+    res["end_to_end_ms"] = timed(e2e, steps)
+    res["end_to_end_pairs_per_s"] = pairs / (res["end_to_end_ms"] * 1e-3)
+    # after the last gather every rank must hold the whole matrix: check blocks from every rank's rows + checksum
+    fails = check_outputs(xyz, mask, out_d, out_m, n_blocks=128, seed=11 + rank)
+    res["check_after_gather"] = "ok" if not fails else fails
+    recompute = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather="recompute", out_dist=out_d, out_mask=out_m)
+    res["full_matrix_recomputed_per_rank_ms"] = timed(recompute, steps)
+    res["allgather_best_ms"] = best
     return res
 
 
@@ -140,6 +240,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rowshard", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run verification of the timed buffers")
     ap.add_argument("--shop-allocations", type=int, default=0,
                     help="opt-in experiment: pick the fastest of K output allocations (reported in config); default off")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for rehearsals)")
@@ -166,8 +267,9 @@ def main():
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         kw = {"device_id": dev} if args.backend == "nccl" else {}
-        dist.init_process_group(args.backend, timeout=datetime.timedelta(seconds=300), **kw)
+        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
 
     def max_over_ranks(values):
         """Element-wise max of a list of floats over all ranks (object collective: works on any backend)."""
@@ -179,7 +281,7 @@ def main():
 
     from protstruc_amd import _lib, ops
 
-    _lib.load()  # fails loudly if the HIP library is missing
+    _lib.load()  # fails loudly if the HIP library is missing, stale or of another ABI version
     xyz_cpu, mask_cpu = synth(seed=rank)  # rank 0 / N=1: seed 0 as in SURVEY 8(d)
     xyz, mask = xyz_cpu.to(dev), mask_cpu.to(dev)
     shop_report = None
@@ -197,6 +299,9 @@ def main():
     ops.autotune_pairwise_distance(xyz, mask, out_d, out_m)  # one-time per-device library initialisation (not a step)
     for _ in range(args.warmup):
         step()
+    # the check below must see what the TIMED launches wrote, not what warm-up left behind
+    out_d.fill_(float("nan"))
+    out_m.fill_(False)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
@@ -216,32 +321,55 @@ def main():
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
     elapsed, kernel_ms_max = max_over_ranks([elapsed, kernel_ms])
 
+    # ---- verification of the timed buffers (outside the timed region) ----
+    if args.no_check:
+        check = "skipped (--no-check)"
+    else:
+        fails = check_outputs(xyz, mask, out_d, out_m)
+        all_fails = fails
+        if dist:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, fails)
+            all_fails = [f"rank {r}: {f}" for r, fl in enumerate(gathered) for f in fl]
+        if all_fails:
+            print("bench.py: the timed outputs are WRONG -- no result line is emitted:\n  " + "\n  ".join(all_fails),
+                  file=sys.stderr, flush=True)
+            os._exit(5)
+        check = "ok"
+
     pairs_per_step = B * N_RES * N_RES * world
     value = pairs_per_step * args.steps / elapsed
     achieved = B * N_RES * N_RES * BYTES_PER_PAIR / (kernel_ms_max * 1e-3) / 1e9
-    traffic = load_traffic()
+    traffic, traffic_source = load_traffic()
     result = {
         "metric": "residue-pairs/sec on pairwise_distance_matrix (B=64,N=512); % HBM roofline",
         "value": value, "unit": "residue-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "check": check,
+        "check_what": "64 sampled (b,i,j) blocks of the timed buffers vs the fp32 formula <= 1e-5 and their mask blocks "
+                      "exactly; exact mask checksum of every structure; bitwise symmetry of one whole structure; buffers "
+                      "were NaN/False-filled before the timed launches",
         "config": {"workload": "pairwise_distance_matrix B=64 N_res=512 N_atom=15 (dist fp32 + bool mask), per GPU",
                    "global_batch": B * world, "n_res": N_RES, "n_atom": N_ATOM,
                    "parallelism": "replicas-of-batch" if world > 1 else "single-gpu",
-                   "k1_tuning": {k: _lib.get_tuning(k) for k in ("k1_variant", "k1_jt", "k1_rows_per_block", "k1_store_nt",
-                                                                 "k1_xcd_remap", "k1_exact_sqrt", "k1_lds_pad_kb")},
-                   "k1_sqrt": ("correctly rounded" if _lib.get_tuning("k1_exact_sqrt")
+                   "k1_tuning": _lib.all_tuning(dev),     # every knob the timed launches ran with
+                   "library": {"abi": _lib.load().ps_abi_version(), "experiments_compiled_in": bool(_lib.load().ps_has_experiments())},
+                   "k1_sqrt": ("correctly rounded" if _lib.get_tuning("k1_exact_sqrt", dev)
                                else "hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise; parity gate 1e-5 abs)"),
                    "k1_autotune": ops.k1_autotune_result(dev),
                    "output_allocation": ("torch.empty (default)" if shop_report is None
                                          else {"best_of": args.shop_allocations, **shop_report})},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                     "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "k1_pairdist_a15_pat", "kernel_ms": kernel_ms_max,
                      "algorithmic_bytes_per_launch": B * N_RES * N_RES * BYTES_PER_PAIR,
                      "frac_of_measured_write_ceiling_6.88TBps": achieved / 6880.0},
         "pct_hbm_roofline": 100.0 * achieved / HBM_PEAK_GBPS,
     }
+    if dist:
+        result["rccl_ranks"] = world if args.backend == "nccl" else 0
+        result["dist_backend"] = args.backend
 
     printed = threading.Event()
 
@@ -255,28 +383,47 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(xyz_cpu, mask_cpu)
         result["gpu_over_cpu"] = value / result["cpu_baseline"]["value"]
+        result["gpu_over_cpu_single_thread"] = value / result["cpu_baseline"]["single_thread"]["value"]
 
+    exit_code = 0
     if (world > 1 or force_dist) and not args.no_rowshard:
-        # The aux section must never cost the main line: a watchdog prints it and exits if RCCL stalls.
+        # A stalled collective or hung kernel must not look like success: the watchdog prints the main line (the
+        # headline measurement above is complete and valid) and then ends EVERY rank with a non-zero code.
         def watchdog():
-            time.sleep(240)
-            result["rowshard_allgather"] = {"error": "timed out after 240 s"}
+            time.sleep(420)
+            result["rowshard_allgather"] = None
+            result["rowshard_error"] = "timed out after 420 s (stalled collective or kernel)"
             emit()
-            os._exit(0)
+            os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         del out_d, out_m
         torch.cuda.empty_cache()
         try:
-            result["rowshard_allgather"] = rowshard_allgather(dev, rank, world, max_over_ranks)
-        except Exception as exc:  # noqa: BLE001 -- report, do not lose the main measurement
-            result["rowshard_allgather"] = {"error": f"{type(exc).__name__}: {exc}"}
+            rs = rowshard_allgather(dev, rank, world, max_over_ranks, args.backend, shared_gpu=world > n_dev)
+            result["rowshard_allgather"] = rs
+            errs = [f"{k}: {v}" for k, v in rs.items() if k.endswith("_error")]
+            if rs.get("check_after_gather") != "ok":
+                errs.append(f"check_after_gather: {rs.get('check_after_gather')}")
+            if errs:
+                result["rowshard_error"] = "; ".join(errs)
+                exit_code = 4
+        except Exception as exc:  # noqa: BLE001 -- the main measurement is still printed, the failure is not hidden
+            result["rowshard_allgather"] = None
+            result["rowshard_error"] = f"{type(exc).__name__}: {exc}"
+            exit_code = 4
     emit()
-    if dist:
+    if dist and exit_code == 0:
         try:
+            from protstruc_amd import distributed as D
+            D.destroy_native_comms()
             dist.destroy_process_group()
         except Exception:  # noqa: BLE001
             pass
+    if exit_code:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(exit_code)     # on every rank; no teardown of a possibly wedged communicator
 
 
 if __name__ == "__main__":

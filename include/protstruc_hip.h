@@ -19,6 +19,9 @@
  *   - `stream` is a `hipStream_t` passed as `void*` (NULL = the default stream);
  *   - launches are asynchronous, perform no allocation, no synchronisation and
  *     no host read of device memory, so they may be captured into a hipGraph;
+ *   - the library holds no mutable state (no tuning globals, no caches, no handles):
+ *     every entry point is re-entrant and may be called concurrently from any
+ *     number of threads, devices and streams;
  *   - the return value is a `hipError_t` as int (0 = success); argument errors
  *     return hipErrorInvalidValue (1) before anything is launched.
  */
@@ -33,26 +36,47 @@ extern "C" {
 
 #define PS_RNG_STATE_WORDS 528
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change); ps_abi_version() returns the library's. */
+#define PS_ABI_VERSION 2
 int ps_abi_version(void);
+
+/* 0 for the product library.  1 for builds made with -DPS_EXPERIMENTS (tools/ only), which contain timing
+ * experiments that can write wrong values; those are unreachable -- not compiled -- in the product build. */
+int ps_has_experiments(void);
 
 /* Human-readable text for a code returned by any ps_* function. */
 const char* ps_error_string(int code);
 
 /*
- * Tuning knob for experiments (store policy, tile shapes).  Unknown keys return
- * hipErrorInvalidValue.  Keys: "k1_store_nt" (0/1), "k1_rows_per_block" (1..32),
- * "k1_variant" (0 = pattern kernels, 1 = slot-decode kernel everywhere), "k1_jt" (64/128, 0 = auto),
- * "k1_flat" (flat kernels: 0 never, 1 where they are the fast path, 2 / 3 force the A = 15 / any-A flat kernel),
- * "k1_anya_fl_log2" (any-A kernel chunk length, 0 = auto), "k1_flat_cpw" (chunks per workgroup,
- * 1..64), "k1_xcd_remap" (0/1), "k1_unroll" (0/1), "k1_lds_pad_kb" / "k1_flat_lds_pad_kb" (idle LDS per workgroup = residency cap),
- * "k1_exact_sqrt" (K1 square root: 0 = hardware v_sqrt_f32, at most 1 ulp off; 1 = correctly rounded),
- * "k1_math" (pattern-kernel experiments: 0 = product arithmetic, 1 = force the hardware sqrt, 2 = store-only timing
- * run that produces WRONG values, 3 = the first correctly rounded routine).
- * Not part of the drop-in surface; has no reference counterpart.
+ * Launch configuration of K1.  The library holds NO mutable state: every launcher is a pure function of its
+ * arguments, so two threads / two devices / two streams of one process can never see each other's settings.
+ * A NULL configuration (and ps_pairwise_distance_f32, which takes none) means ps_k1_config_default().
+ * Every setting produces the same bits (the two square-root modes differ by at most 1 ulp); the knobs only move
+ * work between kernels and change the granule a workgroup writes.  Not part of the drop-in surface; no reference
+ * counterpart.
  */
-int ps_set_tuning(const char* key, int value);
-int ps_get_tuning(const char* key, int* value);
+typedef struct ps_k1_config {
+    int struct_size;      /* = sizeof(ps_k1_config); a launcher refuses any other value (caller built against another header) */
+    int exact_sqrt;       /* 0: hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise); 1: correctly rounded */
+    int variant;          /* 0: fast kernels (pattern / flat pattern / fixed-A flat / any-A flat); 1: the simple kernels
+                             everywhere (slot-decode kernel for A = 15, element-per-lane kernel otherwise) */
+    int flat;             /* flat kernels: 0 never; 1 where they are the fast path (default); 2 force the A = 15 flat
+                             pattern kernel; 3 force the any-A flat kernel; 4 force the fixed-A flat pattern kernel */
+    int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1) */
+    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 */
+    int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
+    int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
+    int jt;               /* pattern kernel: column residues per tile, 64 / 128, 0 = auto */
+    int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
+    int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
+    int anya_fl_log2;     /* any-A flat kernel: log2(pairs per chunk), 0 = auto */
+    int experiment;       /* must be 0 in the product library; timing experiments exist only in builds made with
+                             -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
+                             run that writes WRONG values, +16 = fully unrolled group loop */
+} ps_k1_config;
+
+/* Fills *cfg with the defaults listed above (struct_size included). */
+void ps_k1_config_default(ps_k1_config* cfg);
 
 /*
  * K1 -- replaces StructureBatch.pairwise_distance_matrix (protstruc.py:455-484).
@@ -71,7 +95,7 @@ int ps_get_tuning(const char* key, int* value);
  * plane not produced); `dist` may be NULL (only the mask plane produced).
  * Arithmetic: sqrt((dx*dx + dy*dy) + dz*dz) in fp32 without contraction; the square
  * root is the hardware instruction (exact for 85 % of inputs, 1 ulp off otherwise)
- * unless ps_set_tuning("k1_exact_sqrt", 1) selects the correctly rounded routine.
+ * unless ps_k1_config.exact_sqrt selects the correctly rounded routine.
  */
 int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask,
                              float* dist, uint8_t* dist_mask,
@@ -79,6 +103,14 @@ int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask,
                              int row_begin, int row_end,
                              int out_rows, int out_row_origin,
                              void* stream);
+
+/* The same with an explicit launch configuration (NULL = defaults). */
+int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask,
+                                 float* dist, uint8_t* dist_mask,
+                                 int B, int N, int A,
+                                 int row_begin, int row_end,
+                                 int out_rows, int out_row_origin,
+                                 const ps_k1_config* cfg, void* stream);
 
 /*
  * K2 -- replaces StructureBatch.backbone_dihedrals together with

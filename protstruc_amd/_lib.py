@@ -5,9 +5,20 @@ fails, the caller gets an exception -- never a silent CPU / eager-PyTorch path.
 """
 import ctypes
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libprotstruc_hip.so")
+# PROTSTRUC_AMD_LIB selects another build of the same sources (tools/ use the -DPS_EXPERIMENTS one)
+LIB_PATH = os.environ.get("PROTSTRUC_AMD_LIB") or os.path.join(_HERE, "lib", "libprotstruc_hip.so")
+EXPECTED_ABI = 2  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
+
+
+class K1Config(ctypes.Structure):
+    """``ps_k1_config`` of include/protstruc_hip.h, field for field."""
+    _fields_ = [(name, ctypes.c_int) for name in (
+        "struct_size", "exact_sqrt", "variant", "flat", "rows_per_block", "lds_pad_kb", "flat_cpw",
+        "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "anya_fl_log2", "experiment")]
+
 
 _c_f32p = ctypes.c_void_p
 _c_u8p = ctypes.c_void_p
@@ -18,10 +29,12 @@ _c_stream = ctypes.c_void_p
 SIGNATURES = {
     "ps_abi_version": (_c_int, []),
     "ps_error_string": (ctypes.c_char_p, [_c_int]),
-    "ps_set_tuning": (_c_int, [ctypes.c_char_p, _c_int]),
-    "ps_get_tuning": (_c_int, [ctypes.c_char_p, ctypes.POINTER(_c_int)]),
+    "ps_has_experiments": (_c_int, []),
+    "ps_k1_config_default": (None, [ctypes.POINTER(K1Config)]),
     "ps_pairwise_distance_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                           _c_int, _c_int, _c_stream]),
+    "ps_pairwise_distance_cfg_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_int, _c_int, _c_int, _c_int, _c_int,
+                                              _c_int, _c_int, ctypes.POINTER(K1Config), _c_stream]),
     "ps_backbone_dihedrals_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_u8p, _c_u8p, _c_int, _c_int,
                                            _c_int, _c_stream]),
     "ps_pairwise_angles_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
@@ -57,8 +70,6 @@ def _try_build_in_tree():
     (hipcc is part of the ROCm image).  Never a fallback to another code path: if this fails, load() raises."""
     from . import build
 
-    if os.path.abspath(LIB_PATH) != os.path.abspath(build.LIB_PATH) or os.environ.get("PROTSTRUC_AMD_NO_AUTOBUILD"):
-        return
     if not os.path.exists(build.HIPCC):
         return
     try:
@@ -72,21 +83,35 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    from . import build
+
+    in_tree = os.path.abspath(LIB_PATH) == os.path.abspath(build.LIB_PATH)
+    if in_tree and build.is_stale() and not os.environ.get("PROTSTRUC_AMD_NO_AUTOBUILD"):
+        # missing, or older than csrc/*.hip / include/*.h: rebuild in place (hipcc is part of the ROCm image).
+        # Without hipcc a stale library is refused below rather than loaded.
         _try_build_in_tree()
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} is missing: build it with `python -m protstruc_amd.build` "
             "(hipcc --offload-arch=gfx950). protstruc_amd has no CPU fallback.")
+    if in_tree and build.is_stale():
+        raise HipLibraryError(
+            f"{LIB_PATH} is older than its sources (csrc/*.hip, include/*.h) and could not be rebuilt here: "
+            "run `python -m protstruc_amd.build --force` where hipcc is available.")
     lib = ctypes.CDLL(LIB_PATH)
+    try:
+        lib.ps_abi_version.restype = _c_int
+        abi = lib.ps_abi_version()
+    except AttributeError as exc:
+        raise HipLibraryError(f"{LIB_PATH} does not export ps_abi_version: not a protstruc_amd library") from exc
+    if abi != EXPECTED_ABI:
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {abi}, this package binds version {EXPECTED_ABI}: "
+                              "rebuild with `python -m protstruc_amd.build --force`")
     for name, (restype, argtypes) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
-    # K1 uses the hardware square root (<= 1 ulp) unless the user asks for the correctly rounded one
-    if os.environ.get("PROTSTRUC_AMD_EXACT_SQRT", "0") not in ("", "0"):
-        lib.ps_set_tuning(b"k1_exact_sqrt", 1)
     return lib
 
 
@@ -96,11 +121,84 @@ def check(code, what):
         raise HipLibraryError(f"{what} failed: hipError {code} ({msg.decode() if msg else '?'})")
 
 
-def set_tuning(key, value):
-    check(load().ps_set_tuning(key.encode(), int(value)), f"ps_set_tuning({key})")
+# ---- K1 launch configuration: a per-device table on the HOST side --------------------------------------------------
+# The library itself is stateless (every launch takes its configuration as an argument).  What the Python shell keeps
+# is one small dict per device -- the autotuner's choice for that device's output buffers, plus whatever a test or
+# tool set explicitly -- guarded by a lock and snapshotted into a fresh struct for every launch, so a thread that
+# changes a knob can never tear the configuration another thread is launching with.
+_K1_KEYS = {   # tuning key -> (struct field, lowest, highest)
+    "k1_exact_sqrt": ("exact_sqrt", 0, 1), "k1_variant": ("variant", 0, 1), "k1_flat": ("flat", 0, 4),
+    "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", 0, 120),
+    "k1_flat_cpw": ("flat_cpw", 1, 64), "k1_flat_lds_pad_kb": ("flat_lds_pad_kb", 0, 100),
+    "k1_jt": ("jt", 0, 128), "k1_xcd_remap": ("xcd_remap", 0, 1), "k1_store_nt": ("store_nt", 0, 1),
+    "k1_anya_fl_log2": ("anya_fl_log2", 0, 10), "k1_experiment": ("experiment", 0, 31),
+}
+_k1_lock = threading.RLock()
+_k1_table = {}   # device index -> {field: value}
 
 
-def get_tuning(key):
-    v = ctypes.c_int(0)
-    check(load().ps_get_tuning(key.encode(), ctypes.byref(v)), f"ps_get_tuning({key})")
-    return v.value
+def _device_index(device=None):
+    if device is None:
+        import torch
+        return torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if isinstance(device, int):
+        return device
+    import torch
+    d = torch.device(device)
+    return d.index if d.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+
+
+def _k1_defaults():
+    cfg = K1Config()
+    load().ps_k1_config_default(ctypes.byref(cfg))
+    d = {f: getattr(cfg, f) for f, _ in K1Config._fields_}
+    # K1 uses the hardware square root (<= 1 ulp) unless the user asks for the correctly rounded one
+    if os.environ.get("PROTSTRUC_AMD_EXACT_SQRT", "0") not in ("", "0"):
+        d["exact_sqrt"] = 1
+    return d
+
+
+def _k1_entry(device):
+    idx = _device_index(device)
+    with _k1_lock:
+        if idx not in _k1_table:
+            _k1_table[idx] = _k1_defaults()
+        return _k1_table[idx]
+
+
+def k1_config(device=None, **overrides):
+    """Snapshot of ``device``'s K1 configuration as a ``ps_k1_config`` struct (fields overridden by keyword)."""
+    with _k1_lock:
+        d = dict(_k1_entry(device))
+    d.update(overrides)
+    return K1Config(**d)
+
+
+def set_tuning(key, value, device=None):
+    """Set one K1 knob for ``device`` (default: the current device).  Host-side state only."""
+    value = int(value)
+    if key not in _K1_KEYS:
+        raise HipLibraryError(f"unknown tuning key {key!r} (known: {', '.join(sorted(_K1_KEYS))})")
+    field, lo, hi = _K1_KEYS[key]
+    if not lo <= value <= hi or (key == "k1_jt" and value not in (0, 64, 128)) \
+            or (key == "k1_anya_fl_log2" and value in (1, 2, 3)):
+        raise HipLibraryError(f"tuning value {key}={value} outside its range")
+    if key == "k1_experiment" and value and not load().ps_has_experiments():
+        raise HipLibraryError("timing experiments are not compiled into the product library "
+                              "(build with `python -m protstruc_amd.build --experiments` and set PROTSTRUC_AMD_LIB)")
+    with _k1_lock:
+        _k1_entry(device)[field] = value
+
+
+def get_tuning(key, device=None):
+    if key not in _K1_KEYS:
+        raise HipLibraryError(f"unknown tuning key {key!r}")
+    with _k1_lock:
+        return _k1_entry(device)[_K1_KEYS[key][0]]
+
+
+def all_tuning(device=None):
+    """Every K1 knob of ``device`` as a dict (what ``bench.py`` reports)."""
+    with _k1_lock:
+        e = dict(_k1_entry(device))
+    return {key: e[field] for key, (field, _, _) in sorted(_K1_KEYS.items())}

@@ -159,17 +159,15 @@ extern "C" int ps_kabsch_f32(const float* src_xyz, const float* dst_xyz, const u
                              int B, int n_atoms, int dst_is_shared, int mask_is_shared, void* stream) {
     if (!src_xyz || !dst_xyz || !atom_mask || !R || !t || B < 0 || n_atoms < 0) return (int)hipErrorInvalidValue;
     if (B == 0) return 0;
-    hipLaunchKernelGGL(k_kabsch, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_xyz, dst_xyz,
+    return ps_launch(k_kabsch, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), src_xyz, dst_xyz,
                        atom_mask, R, t, (unsigned)n_atoms, dst_is_shared ? (size_t)0 : (size_t)n_atoms * 3,
                        mask_is_shared ? (size_t)0 : (size_t)n_atoms);
-    return ps_check_launch();
 }
 
 extern "C" int ps_min_dist_to_points_f32(const float* xyz, const float* query, float* out, int N, int A, int atom,
                                          int n_query, void* stream) {
     if (!xyz || !query || !out || N < 0 || A <= 0 || atom < 0 || atom >= A || n_query < 0) return (int)hipErrorInvalidValue;
     if (N == 0) return 0;
-    hipLaunchKernelGGL(k_min_dist, dim3((N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xyz, query,
+    return ps_launch(k_min_dist, dim3((N + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xyz, query,
                        out, (unsigned)N, (unsigned)A, (unsigned)atom, (unsigned)n_query);
-    return ps_check_launch();
 }

@@ -81,8 +81,7 @@ extern "C" int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_id
                                          int B, int N, int A, void* stream) {
     if (!xyz || !chain_idx || !residue_mask || B < 0 || N < 0 || A < 3 || B > 65535) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    hipLaunchKernelGGL(k2_backbone_dihedrals, dim3((N + 255) / 256, B), dim3(256), 0,
+    return ps_launch(k2_backbone_dihedrals, dim3((N + 255) / 256, B), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), xyz, chain_idx, residue_mask, dihedrals, dihedral_mask,
                        nterm, cterm, N, A);
-    return ps_check_launch();
 }

@@ -1,24 +1,21 @@
 // Library-level entry points of libprotstruc_hip.so (see include/protstruc_hip.h).
+// The library keeps no mutable state: there is nothing to initialise, configure or tear down.
 #include <hip/hip_runtime.h>
-#include <string.h>
 
 #include "../../include/protstruc_hip.h"
 
-extern "C" int ps_k1_set_tuning(const char* key, int value);
-extern "C" int ps_k1_get_tuning(const char* key, int* value);
-
-extern "C" int ps_abi_version(void) { return 1; }
+// 2: per-call K1 configuration (ps_k1_config, ps_pairwise_distance_cfg_f32) replaced the process-global
+//    ps_set_tuning / ps_get_tuning of version 1.
+extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 
 extern "C" const char* ps_error_string(int code) { return hipGetErrorString(static_cast<hipError_t>(code)); }
 
-extern "C" int ps_set_tuning(const char* key, int value) {
-    if (!key) return (int)hipErrorInvalidValue;
-    if (!strncmp(key, "k1_", 3)) return ps_k1_set_tuning(key, value);
-    return (int)hipErrorInvalidValue;
-}
-
-extern "C" int ps_get_tuning(const char* key, int* value) {
-    if (!key || !value) return (int)hipErrorInvalidValue;
-    if (!strncmp(key, "k1_", 3)) return ps_k1_get_tuning(key, value);
-    return (int)hipErrorInvalidValue;
+// 1 when the library was built with -DPS_EXPERIMENTS (timing experiments that can write wrong values); the product
+// build returns 0 and refuses any ps_k1_config with experiment != 0.
+extern "C" int ps_has_experiments(void) {
+#ifdef PS_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }

@@ -440,18 +440,16 @@ extern "C" int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_st
     if (n_total >= 0xFFFFFFF0ull) return (int)hipErrorInvalidValue;  // 32-bit index math (17 GB of coordinates)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t groups = (n_total + 3) / 4;
-    hipLaunchKernelGGL(k5_diffuse, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, xyz, beta,
+    return ps_launch(k5_diffuse, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, xyz, beta,
                        (unsigned)n_total, (unsigned)n_per_struct, (unsigned)B, rng_state, noise);
-    return ps_check_launch();
 }
 
 extern "C" int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std, int B, int N, int A,
                                   void* stream) {
     if (!xyz || !mu || !std || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    hipLaunchKernelGGL(k6_standardize, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
+    return ps_launch(k6_standardize, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
                        mu, std, N * A);
-    return ps_check_launch();
 }
 
 extern "C" int ps_affine_f32(float* xyz, const float* scale, const float* shift, int B, int n_atoms_per_struct,
@@ -459,9 +457,8 @@ extern "C" int ps_affine_f32(float* xyz, const float* scale, const float* shift,
     if (!xyz || !scale || !shift || B < 0 || n_atoms_per_struct < 0) return (int)hipErrorInvalidValue;
     const size_t total = (size_t)B * n_atoms_per_struct;
     if (total == 0) return 0;
-    hipLaunchKernelGGL(k6_affine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+    return ps_launch(k6_affine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), xyz, scale, shift, (unsigned)n_atoms_per_struct, total);
-    return ps_check_launch();
 }
 
 extern "C" int ps_diffuse_frames_f32(float* xyz, const float* beta, int B, int N, int A, uint64_t* rng_state,
@@ -479,9 +476,8 @@ extern "C" int ps_diffuse_frames_f32(float* xyz, const float* beta, int B, int N
     const size_t lds = (size_t)RB * A * 3 * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL((k54_diffuse_frames<RB>), dim3((unsigned)((n_res + RB - 1) / RB)), dim3(256), lds, s, xyz, beta,
+    return ps_launch(k54_diffuse_frames<RB>, dim3((unsigned)((n_res + RB - 1) / RB)), dim3(256), lds, s, xyz, beta,
                        (unsigned)n_res, (unsigned)N, (unsigned)A, rng_state, noise, rot, trans, a1, a2, a3, t_atom);
-    return ps_check_launch();
 }
 
 extern "C" int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, int N, int A,
@@ -496,8 +492,7 @@ extern "C" int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T
     constexpr int RB = 128;
     const size_t lds = (size_t)RB * A * 3 * sizeof(float);
     if (lds > 150 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL((k55_diffusion_trajectory<RB>), dim3((unsigned)((n_res + RB - 1) / RB)), dim3(256), lds,
+    return ps_launch(k55_diffusion_trajectory<RB>, dim3((unsigned)((n_res + RB - 1) / RB)), dim3(256), lds,
                        reinterpret_cast<hipStream_t>(stream), xyz, betas, (unsigned)T, (unsigned)n_res, (unsigned)N,
                        (unsigned)A, rng_state, rot, trans, xyz_traj, a1, a2, a3, t_atom);
-    return ps_check_launch();
 }

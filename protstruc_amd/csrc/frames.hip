@@ -58,9 +58,8 @@ extern "C" int ps_pointwise_f32(int mode, const float* a, const float* b, const 
                                 long long n, void* stream) {
     if (mode < 0 || mode > 2 || !a || !b || !c || !out || n < 0 || (mode == 1 && !d)) return (int)hipErrorInvalidValue;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    return ps_launch(k_pointwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, b, c, d, out, (size_t)n, mode);
-    return ps_check_launch();
 }
 
 extern "C" int ps_frames_f32(const float* xyz, float* rot, float* trans, int B, int N, int A, int a1, int a2, int a3,
@@ -70,7 +69,6 @@ extern "C" int ps_frames_f32(const float* xyz, float* rot, float* trans, int B, 
     if (trans && (t_atom < 0 || t_atom >= A)) return (int)hipErrorInvalidValue;
     const size_t n_res = (size_t)B * N;
     if (n_res == 0) return 0;
-    hipLaunchKernelGGL(k4_frames, dim3((unsigned)((n_res + 255) / 256)), dim3(256), 0,
+    return ps_launch(k4_frames, dim3((unsigned)((n_res + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), xyz, rot, trans, n_res, A, a1, a2, a3, t_atom);
-    return ps_check_launch();
 }

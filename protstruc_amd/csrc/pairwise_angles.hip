@@ -142,9 +142,8 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const int IR = 16;
     const int rows = row_end - row_begin;
     dim3 grid((N + 255) / 256, (rows + IR - 1) / IR, B);
-    hipLaunchKernelGGL((k3_pairwise_angles<NP, SRC>), grid, dim3(256), 0, s, xyz, out, N, A, sel, row_begin, row_end,
+    return ps_launch(k3_pairwise_angles<NP, SRC>, grid, dim3(256), 0, s, xyz, out, N, A, sel, row_begin, row_end,
                        out_rows, out_row_origin, IR);
-    return ps_check_launch();
 }
 
 template <int NP, int... SRCS>
@@ -194,8 +193,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
     if (B == 0 || N == 0) return 0;
     const int IR = 16;
     if ((N + IR - 1) / IR > 65535) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(k3_inter_residue_geometry, dim3((N + 255) / 256, (N + IR - 1) / IR, B), dim3(256), 0,
+    return ps_launch(k3_inter_residue_geometry, dim3((N + 255) / 256, (N + IR - 1) / IR, B), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
                        d_ca_mask, d_cb_mask, d_no_mask, N, A, IR);
-    return ps_check_launch();
 }

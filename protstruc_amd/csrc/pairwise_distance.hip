@@ -27,36 +27,19 @@
 // N < 16, unaligned planes and as the bit-identity cross-check in the tests.
 // Any A other than 15 takes the generic element-per-lane kernel at the bottom.
 #include "ps_common.hpp"
-#include <string.h>
+#include "../../include/protstruc_hip.h"
 
 namespace {
 
 constexpr int A15 = 15;
 constexpr int AA15 = 225;
 
-struct K1Tuning {
-    // Measured on MI355X at B=64, N=512 (tools/k1_probe.py): plain stores beat non-temporal ones for the
-    // pattern kernel (its 3600-byte groups are not 128-byte aligned, so lines are completed by a second
-    // wave and want to merge in L2), and one row per workgroup (small granules written in address order)
-    // beats 4..16 rows.
-    int store_nt = 0;
-    int exact_sqrt = 0;       // 0: hardware sqrt (<= 1 ulp); 1: correctly rounded (see dist_pp)
-    int rows_per_block = 1;   // IR
-    int variant = 0;          // 0: pattern kernel on aligned shapes; 1: slot-decode kernel everywhere
-    int jt = 0;               // column residues per tile: 64, 128, or 0 = auto (128 when N >= 256: ~1 % faster at N = 512)
-    int math = 0;             // experiments on the pattern kernel: 0 product arithmetic (sqrt per exact_sqrt); 1 force the
-                              // hardware sqrt; 2 store-only (WRONG values); 3 the first correctly rounded routine
-    int unroll = 0;           // 1: straight-line code for full tiles of the pattern kernel
-    int xcd_remap = 1;        // pattern kernel: each XCD sweeps its own contiguous eighth of the output (see kernel)
-    int lds_pad_kb = 0;       // extra (idle) dynamic LDS per workgroup: caps resident workgroups per CU; 8 KB (4 -> 3 per CU)
-                              // is an autotune candidate, worth ~2 % on the devices that dislike many concurrent streams
-    int flat = 1;             // flat kernels: 0 never; 1 where they are the fast path (A = 15 with N % 16 != 0, every other A);
-                              // 2 A = 15 flat pattern kernel always; 3 any-A flat kernel always (cross-checks)
-    int anya_fl_log2 = 0;     // any-A flat kernel: log2(pairs per chunk), 0 = auto (experiments)
-    int flat_lds_pad_kb = 0;  // the same residency cap for the flat pattern kernel
-    int flat_cpw = 1;         // flat kernel: consecutive 128-pair chunks per workgroup (autotuned per device by ops.py)
-};
-K1Tuning g_k1;
+// Launch configuration: `ps_k1_config` of include/protstruc_hip.h, passed per call.  There is no process-global
+// tuning state in this library (round 1 had one; a second device or thread could overwrite it mid-stream).
+// Measured on MI355X at B=64, N=512 (tools/k1_probe.py): plain stores beat non-temporal ones for the pattern kernel
+// (its 3600-byte groups are not 128-byte aligned, so lines are completed by a second wave and want to merge in
+// L2); which granule per workgroup is fastest depends on the output allocation, so ops.py autotunes it per device.
+using K1Cfg = ps_k1_config;
 
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
@@ -314,16 +297,21 @@ __device__ __forceinline__ float4 lds_atom(const float4* p) {
     return make_float4(v.x, v.y, v.z, v.w);
 }
 
-// MATH: 0 = product arithmetic with the hardware sqrt, 1 = with the correctly rounded sqrt (k1_exact_sqrt);
-//       2 = timing experiment only: stores without any arithmetic (WRONG values);
-//       3 = the first correctly rounded routine (v_sqrt + residual tests; same values as 1).
+// MATH: 0 = product arithmetic with the hardware sqrt, 1 = with the correctly rounded sqrt (cfg.exact_sqrt).
+// Builds made with -DPS_EXPERIMENTS (tools/ only, never the product library) add two timing experiments:
+//       2 = stores without any arithmetic (WRONG values);  3 = the first correctly rounded routine (same values as 1).
 template <int MATH>
 __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
-    if (MATH == 0) return dist_pp<false>(p, q);
-    if (MATH == 1) return dist_pp<true>(p, q);
-    float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    return sqrt_rn_pos((sx + sy) + sz);  // MATH == 3: the first correctly rounded routine (same values as 1)
+#ifdef PS_EXPERIMENTS
+    if (MATH == 3) {
+        float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
+        float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+        return sqrt_rn_pos((sx + sy) + sz);
+    }
+#else
+    static_assert(MATH == 0 || MATH == 1, "experiment modes are compiled only with -DPS_EXPERIMENTS");
+#endif
+    return MATH == 0 ? dist_pp<false>(p, q) : dist_pp<true>(p, q);
 }
 
 template <int JT, bool NT, int MATH, bool UNROLL>
@@ -410,10 +398,13 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             const float4* xj = sxj;
             auto group = [&](int g) {
                 uint4 u;
-                if (MATH == 2) {
+#ifdef PS_EXPERIMENTS
+                if (MATH == 2) {  // store-only timing run: WRONG values by design
                     u = make_uint4(__float_as_uint(pi[0].x), __float_as_uint(pi[1].x), __float_as_uint(pi[2].x),
                                    (unsigned)g);
-                } else {
+                } else
+#endif
+                {
                     const float4* x = xj + g * (4 * RS);
                     const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
                     const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
@@ -946,99 +937,82 @@ __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restri
 }
 
 template <int JT>
-int launch_a15(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int row_begin,
-               int row_end, int out_rows, int out_row_origin, hipStream_t s) {
-    const int IR = g_k1.rows_per_block;
+int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
+               int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+    const int IR = g.rows_per_block;
     const int rows = row_end - row_begin;
     dim3 grid((N + JT - 1) / JT, (rows + IR - 1) / IR, B);
     size_t lds = (size_t)(JT + IR) * A15 * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t);
     const bool da = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(dist) & 15) == 0);
     const bool ma = (N % 16 == 0) && ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0);
-#define PS_K1_LAUNCH1(NT_, DA_, MA_, EX_)                                                                            \
-    hipLaunchKernelGGL((k1_pairdist_a15<JT, NT_, DA_, MA_, EX_>), grid, dim3(256), lds, s, xyz, amask, dist, dmask, N, \
-                       row_begin, row_end, out_rows, out_row_origin, IR)
-#define PS_K1_LAUNCH(NT_, DA_, MA_)                                                                                  \
-    do {                                                                                                             \
-        if (g_k1.exact_sqrt) PS_K1_LAUNCH1(NT_, DA_, MA_, true);                                                     \
-        else PS_K1_LAUNCH1(NT_, DA_, MA_, false);                                                                    \
-    } while (0)
-    if (da && ma && g_k1.variant == 0) {
+    const bool ex = g.exact_sqrt != 0;
+#define PS_K1_LAUNCH1(NT_, DA_, MA_, EX_)                                                                         \
+    ps_launch(k1_pairdist_a15<JT, NT_, DA_, MA_, EX_>, grid, dim3(256), lds, s, xyz, amask, dist, dmask, N,       \
+              row_begin, row_end, out_rows, out_row_origin, IR)
+#define PS_K1_LAUNCH(NT_, DA_, MA_) (ex ? PS_K1_LAUNCH1(NT_, DA_, MA_, true) : PS_K1_LAUNCH1(NT_, DA_, MA_, false))
+    if (da && ma && g.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
-                               (size_t)g_k1.lds_pad_kb * 1024;
+                               (size_t)g.lds_pad_kb * 1024;
         const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        const int remap = (g_k1.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
-#define PS_K1_PAT(NT_, M_, U_)                                                                                     \
-    hipLaunchKernelGGL((k1_pairdist_a15_pat<JT, NT_, M_, U_>), dim3((unsigned)n_wg), dim3(256), lds_pat, s, xyz,    \
-                       amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, (int)grid.x,       \
-                       (int)grid.y, remap)
-        const bool ex = g_k1.exact_sqrt != 0;
-        if (g_k1.math == 1) PS_K1_PAT(false, 0, false);
-        else if (g_k1.math == 3) PS_K1_PAT(false, 3, false);
-        else if (g_k1.math == 2 && g_k1.unroll) PS_K1_PAT(false, 2, true);
-        else if (g_k1.math == 2) PS_K1_PAT(false, 2, false);
-        else if (g_k1.store_nt && ex) PS_K1_PAT(true, 1, false);
-        else if (g_k1.store_nt) PS_K1_PAT(true, 0, false);
-        else if (g_k1.unroll && ex) PS_K1_PAT(false, 1, true);
-        else if (g_k1.unroll) PS_K1_PAT(false, 0, true);
-        else if (ex) PS_K1_PAT(false, 1, false);
-        else PS_K1_PAT(false, 0, false);
+        const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
+#define PS_K1_PAT(NT_, M_, U_)                                                                                    \
+    ps_launch(k1_pairdist_a15_pat<JT, NT_, M_, U_>, dim3((unsigned)n_wg), dim3(256), lds_pat, s, xyz, amask,      \
+              dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, (int)grid.x, (int)grid.y, remap)
+#ifdef PS_EXPERIMENTS
+        const int math = g.experiment & 15;
+        const bool unroll = (g.experiment & 16) != 0;
+        if (math == 1) return PS_K1_PAT(false, 3, false);
+        if (math == 2) return unroll ? PS_K1_PAT(false, 2, true) : PS_K1_PAT(false, 2, false);
+        if (unroll) return ex ? PS_K1_PAT(false, 1, true) : PS_K1_PAT(false, 0, true);
+#endif
+        if (g.store_nt) return ex ? PS_K1_PAT(true, 1, false) : PS_K1_PAT(true, 0, false);
+        return ex ? PS_K1_PAT(false, 1, false) : PS_K1_PAT(false, 0, false);
 #undef PS_K1_PAT
-    } else if (da && ma) {
-        if (g_k1.store_nt) PS_K1_LAUNCH(true, true, true);
-        else PS_K1_LAUNCH(false, true, true);
-    } else if (da) {
-        PS_K1_LAUNCH(true, true, false);
-    } else {
-        PS_K1_LAUNCH(true, false, false);
     }
+    if (da && ma) return g.store_nt ? PS_K1_LAUNCH(true, true, true) : PS_K1_LAUNCH(false, true, true);
+    if (da) return PS_K1_LAUNCH(true, true, false);
+    return PS_K1_LAUNCH(true, false, false);
 #undef PS_K1_LAUNCH
 #undef PS_K1_LAUNCH1
-    return ps_check_launch();
 }
 
 // Flat pattern kernel over the output pair range [pbeg, pend) (pair index P = (b*out_rows + il)*N + j).
-bool flat_eligible(const float* dist, const uint8_t* dmask, int B, int N, int out_rows) {
-    if (g_k1.variant != 0 || g_k1.flat == 0) return false;
+bool flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int out_rows) {
+    if (g.variant != 0 || g.flat == 0) return false;
     if (N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
     if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;  // pair indices stay 32-bit
     if ((unsigned long long)B * N * (A15 * 3) >= 0x80000000ull) return false;  // and so do coordinate indices
     if ((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15)) return false;
-    return g_k1.flat == 2 || N % 16 != 0;
+    return g.flat == 2 || N % 16 != 0;
 }
 
-int launch_a15_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int out_rows,
-                    int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges, unsigned range_stride,
-                    hipStream_t s) {
+int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
+                    int N, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
+                    unsigned range_stride, hipStream_t s) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     // chunks per range: exact for one range, an upper bound when the ranges start at different 128-pair phases
     const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> 7) - (pbeg >> 7) : ((pend - pbeg) >> 7) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    // like rows_per_block this is a per-device matter: four chunks per workgroup are 1-2 % faster on some GPUs and
-    // 8 % slower on others (profiles/r01_k1_ab_flat_cpw.log), so the default is 1 and ops.py autotunes it
-    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g_k1.flat_cpw : 1u;
+    // like rows_per_block this depends on the output allocation: four chunks per workgroup are 1-2 % faster on some
+    // and 8 % slower on others (profiles/r01_k1_ab_flat_cpw.log), so the default is 1 and ops.py autotunes it
+    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g.flat_cpw : 1u;
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
-    const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
-    const size_t pad = (size_t)g_k1.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap (see K1Tuning)
-#define PS_K1_FLAT(EX_, HM_)                                                                                       \
-    hipLaunchKernelGGL((k1_pairdist_a15_flat<EX_, HM_>), dim3(n_wg), dim3(256), pad, s, xyz, amask, dist, dmask, B, N, \
-                       out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
-    if (g_k1.exact_sqrt) {
-        if (amask) PS_K1_FLAT(true, true);
-        else PS_K1_FLAT(true, false);
-    } else {
-        if (amask) PS_K1_FLAT(false, true);
-        else PS_K1_FLAT(false, false);
-    }
+    const size_t pad = (size_t)g.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap
+#define PS_K1_FLAT(EX_, HM_)                                                                                      \
+    ps_launch(k1_pairdist_a15_flat<EX_, HM_>, dim3(n_wg), dim3(256), pad, s, xyz, amask, dist, dmask, B, N,       \
+              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
+    if (g.exact_sqrt) return amask ? PS_K1_FLAT(true, true) : PS_K1_FLAT(true, false);
+    return amask ? PS_K1_FLAT(false, true) : PS_K1_FLAT(false, false);
 #undef PS_K1_FLAT
-    return ps_check_launch();
 }
 
 // Any-A flat kernel: chunk length (a power of two, >= 16 pairs) so that the LDS image stays near 40 KB.
-bool anyA_eligible(const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
-    if (g_k1.variant != 0 || g_k1.flat == 0) return false;
+bool anyA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
+    if (g.variant != 0 || g.flat == 0) return false;
     // A < 4: a chunk's output is smaller than its LDS image and the element kernel is no slower
     if (A < 4 || A > 64 || N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
     if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;
@@ -1047,15 +1021,15 @@ bool anyA_eligible(const float* dist, const uint8_t* dmask, int B, int N, int A,
     return true;
 }
 
-int launch_anyA_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N, int A,
-                     int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
-                     unsigned range_stride, hipStream_t s) {
+int launch_anyA_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
+                     int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
+                     unsigned n_ranges, unsigned range_stride, hipStream_t s) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     // largest power of two of pairs (16..256) whose LDS image (A float4 + A*A/8 bytes of mask bits per pair) stays
     // under 25 KB: measured best or within 2 % of best for A = 4, 5, 8, 14, 16, 25, 37 (profiles/r01_k1_any_a.log)
     int fl_log2 = 4;
     while (fl_log2 < 8 && (size_t)(2 << fl_log2) * ((size_t)A * 16 + (size_t)A * A / 8) <= 25 * 1024) ++fl_log2;
-    if (g_k1.anya_fl_log2) fl_log2 = g_k1.anya_fl_log2;
+    if (g.anya_fl_log2) fl_log2 = g.anya_fl_log2;
     const int FLr = 1 << fl_log2;
     const int FRr = (FLr - 1) / N + 2;
     const unsigned AA = (unsigned)A * A;
@@ -1066,157 +1040,105 @@ int launch_anyA_flat(const float* xyz, const uint8_t* amask, float* dist, uint8_
                                        : ((pend - pbeg) >> fl_log2) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g_k1.flat_cpw : 1u;
+    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g.flat_cpw : 1u;
     const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
-    const int remap = (g_k1.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
-#define PS_K1_ANYA(EX_, HM_)                                                                                        \
-    hipLaunchKernelGGL((k1_pairdist_anyA_flat<EX_, HM_>), dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, \
-                       N, A, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, fl_log2, FRr,       \
-                       (int)cpw, remap, rn, rr)
-    if (g_k1.exact_sqrt) {
-        if (amask) PS_K1_ANYA(true, true);
-        else PS_K1_ANYA(true, false);
-    } else {
-        if (amask) PS_K1_ANYA(false, true);
-        else PS_K1_ANYA(false, false);
-    }
+#define PS_K1_ANYA(EX_, HM_)                                                                                      \
+    ps_launch(k1_pairdist_anyA_flat<EX_, HM_>, dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, N, A,   \
+              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, fl_log2, FRr, (int)cpw, remap,  \
+              rn, rr)
+    if (g.exact_sqrt) return amask ? PS_K1_ANYA(true, true) : PS_K1_ANYA(true, false);
+    return amask ? PS_K1_ANYA(false, true) : PS_K1_ANYA(false, false);
 #undef PS_K1_ANYA
-    return ps_check_launch();
+}
+
+// Range checks of a caller-supplied configuration; the defaults pass by construction.
+bool cfg_valid(const K1Cfg& g) {
+    if (g.struct_size != (int)sizeof(K1Cfg)) return false;
+    if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4) return false;
+    if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < 0 || g.lds_pad_kb > 120) return false;
+    if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
+    if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
+    if (g.anya_fl_log2 != 0 && (g.anya_fl_log2 < 4 || g.anya_fl_log2 > 10)) return false;
+#ifdef PS_EXPERIMENTS
+    if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
+#else
+    if (g.experiment != 0) return false;   // timing experiments do not exist in the product library
+#endif
+    return true;
 }
 
 }  // namespace
 
-extern "C" int ps_k1_set_tuning(const char* key, int value);
-extern "C" int ps_k1_get_tuning(const char* key, int* value);
-
-int ps_k1_set_tuning(const char* key, int value) {
-    if (!strcmp(key, "k1_store_nt")) {
-        g_k1.store_nt = value ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "k1_exact_sqrt")) {
-        g_k1.exact_sqrt = value ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "k1_rows_per_block")) {
-        if (value < 1 || value > 32) return (int)hipErrorInvalidValue;
-        g_k1.rows_per_block = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_variant")) {
-        g_k1.variant = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_xcd_remap")) {
-        g_k1.xcd_remap = value ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "k1_flat_lds_pad_kb")) {
-        if (value < 0 || value > 100) return (int)hipErrorInvalidValue;
-        g_k1.flat_lds_pad_kb = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_lds_pad_kb")) {
-        if (value < 0 || value > 120) return (int)hipErrorInvalidValue;
-        g_k1.lds_pad_kb = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_unroll")) {
-        g_k1.unroll = value ? 1 : 0;
-        return 0;
-    }
-    if (!strcmp(key, "k1_math")) {
-        if (value < 0 || value > 3) return (int)hipErrorInvalidValue;
-        g_k1.math = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_jt")) {
-        if (value != 0 && value != 64 && value != 128) return (int)hipErrorInvalidValue;
-        g_k1.jt = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_flat")) {
-        if (value < 0 || value > 3) return (int)hipErrorInvalidValue;
-        g_k1.flat = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_anya_fl_log2")) {
-        if (value != 0 && (value < 4 || value > 10)) return (int)hipErrorInvalidValue;
-        g_k1.anya_fl_log2 = value;
-        return 0;
-    }
-    if (!strcmp(key, "k1_flat_cpw")) {
-        if (value < 1 || value > 64) return (int)hipErrorInvalidValue;
-        g_k1.flat_cpw = value;
-        return 0;
-    }
-    return (int)hipErrorInvalidValue;
+extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
+    if (!cfg) return;
+    *cfg = ps_k1_config{};
+    cfg->struct_size = (int)sizeof(ps_k1_config);
+    cfg->flat = 1;
+    cfg->rows_per_block = 1;
+    cfg->flat_cpw = 1;
+    cfg->xcd_remap = 1;
 }
 
-int ps_k1_get_tuning(const char* key, int* value) {
-    if (!strcmp(key, "k1_store_nt")) *value = g_k1.store_nt;
-    else if (!strcmp(key, "k1_exact_sqrt")) *value = g_k1.exact_sqrt;
-    else if (!strcmp(key, "k1_rows_per_block")) *value = g_k1.rows_per_block;
-    else if (!strcmp(key, "k1_variant")) *value = g_k1.variant;
-    else if (!strcmp(key, "k1_jt")) *value = g_k1.jt;
-    else if (!strcmp(key, "k1_math")) *value = g_k1.math;
-    else if (!strcmp(key, "k1_unroll")) *value = g_k1.unroll;
-    else if (!strcmp(key, "k1_lds_pad_kb")) *value = g_k1.lds_pad_kb;
-    else if (!strcmp(key, "k1_flat_lds_pad_kb")) *value = g_k1.flat_lds_pad_kb;
-    else if (!strcmp(key, "k1_xcd_remap")) *value = g_k1.xcd_remap;
-    else if (!strcmp(key, "k1_flat")) *value = g_k1.flat;
-    else if (!strcmp(key, "k1_flat_cpw")) *value = g_k1.flat_cpw;
-    else if (!strcmp(key, "k1_anya_fl_log2")) *value = g_k1.anya_fl_log2;
-    else return (int)hipErrorInvalidValue;
-    return 0;
-}
-
-extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask,
-                                        int B, int N, int A, int row_begin, int row_end, int out_rows,
-                                        int out_row_origin, void* stream) {
+extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask, float* dist,
+                                            uint8_t* dist_mask, int B, int N, int A, int row_begin, int row_end,
+                                            int out_rows, int out_row_origin, const ps_k1_config* cfg,
+                                            void* stream) {
     if (!xyz || (!dist && !dist_mask) || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
     if (B > 65535) return (int)hipErrorInvalidValue;
+    K1Cfg g;
+    ps_k1_config_default(&g);
+    if (cfg) {
+        if (!cfg_valid(*cfg)) return (int)hipErrorInvalidValue;
+        g = *cfg;   // by value: the caller may change or free its copy as soon as this call returns
+    }
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
-    if ((A != A15 || g_k1.flat == 3) && anyA_eligible(dist, dist_mask, B, N, A, out_rows)) {
+    if ((A != A15 || g.flat == 3) && anyA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         if (rows == out_rows)
-            return launch_anyA_flat(xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,
+            return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,
                                     (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
         const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
-        return launch_anyA_flat(xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, r0,
+        return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, r0,
                                 r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
     }
-    if (A == A15 && flat_eligible(dist, dist_mask, B, N, out_rows)) {
+    if (A == A15 && flat_eligible(g, dist, dist_mask, B, N, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
         if (rows == out_rows)
-            return launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, 0u,
+            return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, 0u,
                                    (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
         const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
-        return launch_a15_flat(xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
+        return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
     }
     if (A == A15) {
-        if ((rows + g_k1.rows_per_block - 1) / g_k1.rows_per_block > 65535) return (int)hipErrorInvalidValue;
-        const int jt = g_k1.jt ? g_k1.jt : (N >= 256 ? 128 : 64);
+        if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
+        const int jt = g.jt ? g.jt : (N >= 256 ? 128 : 64);
         if (jt == 128)
-            return launch_a15<128>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
-                                   s);
-        return launch_a15<64>(xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+            return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,
+                                   out_row_origin, s);
+        return launch_a15<64>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
+                              s);
     }
     if (rows > 65535) return (int)hipErrorInvalidValue;
     const unsigned long long nE = (unsigned long long)N * A * A;
     if (nE > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
     unsigned gx = (unsigned)((nE + 255) / 256);
     if (gx > 64) gx = 64;
-    if (g_k1.exact_sqrt)
-        hipLaunchKernelGGL(k1_pairdist_generic<true>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
-                           dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
-    else
-        hipLaunchKernelGGL(k1_pairdist_generic<false>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
-                           dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
-    return ps_check_launch();
+    if (g.exact_sqrt)
+        return ps_launch(k1_pairdist_generic<true>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
+                         dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
+    return ps_launch(k1_pairdist_generic<false>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist, dist_mask,
+                     N, A, row_begin, row_end, out_rows, out_row_origin);
+}
+
+extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask,
+                                        int B, int N, int A, int row_begin, int row_end, int out_rows,
+                                        int out_row_origin, void* stream) {
+    return ps_pairwise_distance_cfg_f32(xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows,
+                                        out_row_origin, nullptr, stream);
 }

@@ -9,6 +9,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <tuple>
+#include <utility>
+
 #define PS_WAVE 64
 
 struct f3 {
@@ -182,4 +185,21 @@ __device__ __forceinline__ void gram_schmidt3(f3 a, f3 b, f3 c, f3& e1, f3& e2, 
 
 __device__ __forceinline__ f3 load3(const float* __restrict__ p) { return f3{p[0], p[1], p[2]}; }
 
-static inline int ps_check_launch() { return (int)hipGetLastError(); }
+// Launch `kernel` and return THIS launch's status.  hipLaunchKernel reports the result of the launch it performs;
+// the sticky per-thread "last error" (which unrelated earlier HIP / PyTorch calls may have left set, and which
+// hipGetLastError would both consume and misattribute) is neither read nor cleared.  Arguments are converted to
+// the kernel's exact parameter types before their addresses are taken.
+template <typename... KArgs, size_t... I>
+static inline int ps_launch_impl(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                 std::tuple<KArgs...>& params, std::index_sequence<I...>) {
+    void* ptrs[] = {static_cast<void*>(&std::get<I>(params))...};
+    return (int)hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, lds, stream);
+}
+
+template <typename... KArgs, typename... Args>
+static inline int ps_launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                            Args&&... args) {
+    static_assert(sizeof...(KArgs) == sizeof...(Args), "argument count does not match the kernel's parameter list");
+    std::tuple<KArgs...> params(static_cast<KArgs>(args)...);
+    return ps_launch_impl(kernel, grid, block, lds, stream, params, std::index_sequence_for<KArgs...>{});
+}

@@ -97,17 +97,15 @@ extern "C" int ps_rigid_f32(const float* xyz_in, float* xyz_out, const float* R,
         return (int)hipErrorInvalidValue;
     const size_t n = (size_t)B * N * A;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_rigid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    return ps_launch(k_rigid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        xyz_in, xyz_out, R, t, n, (unsigned)N, (unsigned)A, r_mode, t_mode, transpose);
-    return ps_check_launch();
 }
 
 extern "C" int ps_center_of_mass_f32(const float* xyz, float* com, int B, int N, int A, int atom, void* stream) {
     if (!xyz || !com || B < 0 || N < 0 || A <= 0 || atom < 0 || atom >= A) return (int)hipErrorInvalidValue;
     if (B == 0) return 0;
-    hipLaunchKernelGGL(k_center_of_mass, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), xyz, com,
+    return ps_launch(k_center_of_mass, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), xyz, com,
                        (unsigned)N, (unsigned)A, (unsigned)atom);
-    return ps_check_launch();
 }
 
 extern "C" int ps_frames_to_backbone_f32(const float* rot, const float* trans, const float* ideal, int n_ideal,
@@ -116,7 +114,6 @@ extern "C" int ps_frames_to_backbone_f32(const float* rot, const float* trans, c
         return (int)hipErrorInvalidValue;
     const size_t n = (size_t)B * N * A;
     if (n == 0) return 0;
-    hipLaunchKernelGGL(k_frames_to_backbone, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    return ps_launch(k_frames_to_backbone, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), rot, trans, ideal, xyz, n, (unsigned)A, (unsigned)n_ideal);
-    return ps_check_launch();
 }

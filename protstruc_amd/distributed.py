@@ -1,22 +1,31 @@
-"""Multi-GPU form of the pairwise-distance path: residue rows sharded over ranks.
+"""Multi-GPU form of the pairwise path: residue rows sharded over ranks.
 
-One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).
-``xyz`` / ``atom_mask`` are tiny (180 B per residue) and replicated on every
-rank; only the O(N^2) outputs are sharded.  Rank r computes residue rows
-[r*N/P, (r+1)*N/P) of every structure straight into its slice of a full-size
-(B, N, N, A, A) buffer -- no staging copy -- and, if ``gather`` is set, one
-all-gather per structure (a rank's slice of structure b is one contiguous run)
-reassembles the full matrix on every rank over xGMI.  The gather moves
-(P-1)/P of the whole result into every GPU and is bound by the xGMI links, not
-by the kernel; ``gather=False`` returns the row-sharded result,
-which is what a data-parallel consumer wants.
+One process per GPU (``torch.distributed``; backend "nccl" is RCCL on ROCm).  ``xyz`` / ``atom_mask`` are tiny
+(180 B per residue) and replicated on every rank; only the O(N^2) outputs are sharded.  Rank r computes residue rows
+[r*N/P, (r+1)*N/P) of every structure straight into its slice of a full-size (B, N, N, ...) buffer -- no staging
+copy -- and, if ``gather`` is set, ONE grouped exchange per output plane reassembles the full tensor on every rank
+over xGMI:
 
-The other kernels are per-residue / per-structure: they shard over the batch
-with no exchange ("replicas only").
+* backend "nccl": the native ``ps_allgather_rows`` of libprotstruc_rccl.so (include/protstruc_rccl.h) -- B in-place
+  ``ncclAllGather`` calls (a rank's slice of one structure is one contiguous run) inside one
+  ``ncclGroupStart`` / ``ncclGroupEnd``, on its own communicator created once per process group; uneven splits
+  (N % P != 0) use one in-place ``ncclBroadcast`` per (structure, owner) in the same group;
+* any other backend (gloo rehearsals on CPUs or on one GPU), or ``impl="torch"``: the same exchange through
+  ``torch.distributed`` collectives.
+
+The gather moves (P-1)/P of the whole result into every GPU and is bound by the xGMI links, not by the kernel
+(SURVEY 8(e)); ``gather=False`` returns the row-sharded result, which is what a data-parallel consumer wants, and
+``gather="recompute"`` produces the full tensor on every rank with no collective at all.
+
+Sharded: ``pairwise_distance_matrix`` (reference protstruc.py:455-484) and ``pairwise_dihedrals`` /
+``pairwise_planar_angles`` (protstruc.py:620-660).  The other kernels are per-residue / per-structure: they shard
+over the batch with no exchange ("replicas only").
 """
 from __future__ import annotations
 
-from typing import Optional, Tuple
+import ctypes
+import os
+from typing import Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -25,12 +34,118 @@ from . import ops
 
 
 def shard_rows(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
-    """Balanced contiguous split of ``n_rows`` residue rows: rows [lo, hi) belong to ``rank``."""
+    """Balanced contiguous split of ``n_rows`` residue rows: rows [lo, hi) belong to ``rank``
+    (the same formula as ``ps_shard_rows`` of include/protstruc_rccl.h)."""
     return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
 
 
+# ---- native communicator: one per (process group), created outside any captured region -------------------------
+_COMMS = {}
+
+
+def _group_key(group):
+    return "WORLD" if group is None or group is dist.group.WORLD else id(group)
+
+
+def native_comm(group=None):
+    """The libprotstruc_rccl communicator of ``group`` (created collectively on first use: rank 0 draws the RCCL
+    unique id and ``torch.distributed`` carries it to the other ranks)."""
+    from . import _rccl
+
+    key = _group_key(group)
+    if key in _COMMS:
+        return _COMMS[key]
+    lib = _rccl.load()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ident = [None]
+    if rank == 0:
+        buf = ctypes.create_string_buffer(_rccl.COMM_ID_BYTES)
+        _rccl.check(lib.ps_comm_unique_id(buf), "ps_comm_unique_id")
+        ident[0] = buf.raw
+    src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+    dist.broadcast_object_list(ident, src=src, group=group)
+    comm = ctypes.c_void_p()
+    idbuf = ctypes.create_string_buffer(ident[0], _rccl.COMM_ID_BYTES)
+    _rccl.check(lib.ps_comm_create(ctypes.byref(comm), idbuf, world, rank), "ps_comm_create")
+    _COMMS[key] = comm
+    return comm
+
+
+def destroy_native_comms() -> None:
+    """Release every native communicator (call before ``dist.destroy_process_group()``)."""
+    from . import _rccl
+
+    while _COMMS:
+        _, comm = _COMMS.popitem()
+        _rccl.check(_rccl.load().ps_comm_destroy(comm), "ps_comm_destroy")
+
+
+def _pick_impl(impl: Optional[str], tensor: torch.Tensor, group) -> str:
+    if impl is None:
+        impl = os.environ.get("PROTSTRUC_AMD_GATHER", "auto")
+    if impl not in ("auto", "native", "torch"):
+        raise ValueError(f"impl must be 'auto', 'native' or 'torch', got {impl!r}")
+    if impl == "auto":
+        impl = "native" if (dist.get_backend(group) == "nccl" and tensor.is_cuda) else "torch"
+    if impl == "native" and not tensor.is_cuda:
+        raise ValueError("the native RCCL gather needs device buffers")
+    return impl
+
+
+def allgather_rows(full: torch.Tensor, group=None, impl: Optional[str] = None) -> None:
+    """In-place all-gather of row slices of a contiguous (B, N, ...) tensor: on entry rank r holds rows
+    ``shard_rows(N, r, P)`` of every structure, on return every rank holds all rows."""
+    if full.ndim < 2 or not full.is_contiguous():
+        raise ValueError("allgather_rows needs a contiguous (B, N, ...) tensor")
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1 and impl != "native":
+        return    # (an explicit "native" still goes through the communicator: that is how one GPU rehearses it)
+    B, N = full.shape[:2]
+    row_bytes = full[0, 0].numel() * full.element_size() if full.ndim > 2 else full.element_size()
+    if _pick_impl(impl, full, group) == "native":
+        from . import _rccl
+
+        comm = native_comm(group)
+        with torch.cuda.device(full.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(full.device).cuda_stream)
+            rc = _rccl.load().ps_allgather_rows(comm, ctypes.c_void_p(full.data_ptr()), B, N, row_bytes, stream)
+        _rccl.check(rc, "ps_allgather_rows")
+        return
+    _allgather_rows_torch(full.view(torch.uint8) if full.dtype == torch.bool else full, rank, world, group)
+
+
+def _coalescing(group, device):
+    """torch's grouped-collective context (ncclGroupStart/End underneath) where the backend has one."""
+    import contextlib
+
+    mgr = getattr(dist, "_coalescing_manager", None)
+    if mgr is not None and dist.get_backend(group) == "nccl":
+        return mgr(group=group, device=device, async_ops=False)
+    return contextlib.nullcontext()
+
+
+def _allgather_rows_torch(full: torch.Tensor, rank: int, world: int, group) -> None:
+    B, N = full.shape[:2]
+    lo, hi = shard_rows(N, rank, world)
+    even = (N % world == 0)
+    in_place = even and dist.get_backend(group) == "nccl"
+    with _coalescing(group, full.device):
+        for b in range(B):
+            if even:
+                # equal slices: rank r's rows sit at offset r * (N/world) of structure b -- the in-place
+                # layout ncclAllGather expects (sendbuff == recvbuff + rank * count); gloo wants a separate input
+                mine = full[b, lo:hi]
+                dist.all_gather_into_tensor(full[b], mine if in_place else mine.clone(), group=group)
+            else:
+                for r in range(world):
+                    rlo, rhi = shard_rows(N, r, world)
+                    if rhi > rlo:
+                        src = dist.get_global_rank(group, r) if group is not None and group is not dist.group.WORLD else r
+                        dist.broadcast(full[b, rlo:rhi], src=src, group=group)
+
+
 def pairwise_distance_matrix_sharded(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
-                                     group=None, gather=True,
+                                     group=None, gather=True, impl: Optional[str] = None,
                                      out_dist: Optional[torch.Tensor] = None,
                                      out_mask: Optional[torch.Tensor] = None):
     """Row-sharded ``pairwise_distance_matrix``.
@@ -42,7 +157,9 @@ def pairwise_distance_matrix_sharded(xyz: torch.Tensor, atom_mask: Optional[torc
     on every rank but without any collective: the inputs are replicated, so each
     rank simply computes all rows itself -- one GPU writes the matrix at ~6 TB/s
     while an all-gather receives it at xGMI speed, so this is the faster way to
-    the same bits whenever every rank really needs the whole matrix."""
+    the same bits whenever every rank really needs the whole matrix.
+    ``impl``: "native" (RCCL through libprotstruc_rccl.so; default on the nccl backend), "torch"
+    (torch.distributed collectives; default elsewhere)."""
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     B, N, A = xyz.shape[:3]
@@ -58,25 +175,28 @@ def pairwise_distance_matrix_sharded(xyz: torch.Tensor, atom_mask: Optional[torc
     if out_mask is None:
         out_mask = torch.empty(shape, dtype=torch.bool, device=xyz.device)
     ops.pairwise_distance(xyz, atom_mask, row_begin=lo, row_end=hi, out_dist=out_dist, out_mask=out_mask)
-    if gather and world > 1:
-        _allgather_rows(out_dist, lo, hi, rank, world, group)
-        _allgather_rows(out_mask.view(torch.uint8), lo, hi, rank, world, group)
+    if gather:
+        allgather_rows(out_dist, group, impl)
+        allgather_rows(out_mask, group, impl)
     return out_dist, out_mask, (lo, hi)
 
 
-def _allgather_rows(full: torch.Tensor, lo: int, hi: int, rank: int, world: int, group) -> None:
-    """In-place all-gather of row slices of a (B, N, ...) tensor, one collective per structure."""
-    B, N = full.shape[:2]
-    even = (N % world == 0)
-    in_place = even and dist.get_backend(group) == "nccl"
-    for b in range(B):
-        mine = full[b, lo:hi]
-        if even:
-            # equal slices: rank r's rows sit at offset r * (N/world) of structure b -- the in-place
-            # layout ncclAllGather expects (sendbuff == recvbuff + rank * count)
-            dist.all_gather_into_tensor(full[b], mine if in_place else mine.clone(), group=group)
-        else:
-            for r in range(world):
-                rlo, rhi = shard_rows(N, r, world)
-                if rhi > rlo:
-                    dist.broadcast(full[b, rlo:rhi], src=dist.get_global_rank(group, r) if group else r, group=group)
+def pairwise_angles_sharded(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence[int], n_points: int, *,
+                            group=None, gather=True, impl: Optional[str] = None,
+                            out: Optional[torch.Tensor] = None):
+    """Row-sharded ``pairwise_dihedrals`` (n_points = 4) / ``pairwise_planar_angles`` (n_points = 3): the same row
+    split and the same exchange as the distance matrix, on the (B, N, N) fp32 output.  Returns ``(out, (lo, hi))``."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    B, N = xyz.shape[:2]
+    if gather not in (True, False, "recompute"):
+        raise ValueError(f"gather must be True, False or 'recompute', got {gather!r}")
+    if out is None:
+        out = torch.empty(B, N, N, dtype=torch.float32, device=xyz.device)
+    if gather == "recompute":
+        return ops.pairwise_angles(xyz, slots_i, slots_j, n_points, out=out), (0, N)
+    lo, hi = shard_rows(N, rank, world)
+    ops.pairwise_angles(xyz, slots_i, slots_j, n_points, row_begin=lo, row_end=hi, out=out)
+    if gather:
+        allgather_rows(out, group, impl)
+    return out, (lo, hi)

@@ -9,6 +9,7 @@ CPU path in this package.
 from __future__ import annotations
 
 import ctypes
+import threading
 import time
 from typing import Optional, Sequence, Tuple
 
@@ -82,14 +83,17 @@ def _stream(t: torch.Tensor):
 
 
 # ---- one-time, per-device choice of K1's output granule per workgroup ----------------------------------------
-# MI355X devices differ: with the XCD-contiguous workgroup map, 2-4 residue rows per workgroup run at ~6.25 TB/s
-# on some GPUs and at 4.9-5.4 TB/s on others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log);
-# the flat kernel's chunks-per-workgroup behaves the same way (+1-2 % / -8 %).  The first large call of each kind
-# therefore times the candidates on the caller's own buffers (results are identical for every setting) and keeps
-# the fastest for this process.  Never runs during stream capture.
+# How fast K1's store stream is absorbed depends on the physical memory behind the output buffers (DESIGN.md,
+# "fast and slow allocations"): 2-4 residue rows per workgroup run at ~6.25 TB/s on some and at 4.9-5.4 TB/s on
+# others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log); the flat kernel's chunks per
+# workgroup behaves the same way (+1-2 % / -8 %).  The first large call of each kind on a device therefore times
+# the candidates on the caller's own buffers (results are identical for every setting) and keeps the fastest for
+# that DEVICE: the choice is written to that device's entry of the host-side table in _lib.py and travels to the
+# library as a per-call argument, so other devices and threads are never affected.  Never runs during capture.
 _K1_TUNED = {}
+_K1_TUNE_LOCK = threading.Lock()
 # pattern kernel: (rows per workgroup, KB of idle LDS per workgroup).  The LDS pad only lowers the number of resident
-# workgroups per CU (4 -> 3): on the devices that dislike large granules that is worth ~2 % (fewer concurrent streams).
+# workgroups per CU (4 -> 3): on slow allocations that is worth ~2 % (fewer concurrent streams).
 _K1_CANDIDATE_PATTERN = ((1, 0), (1, 8), (2, 0), (4, 0))
 _K1_CANDIDATE_FLAT = ((1, 0), (1, 8), (2, 0), (4, 0))   # flat kernel: (chunks per workgroup, KB of idle LDS)
 
@@ -106,59 +110,62 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
         return
     if os.environ.get("PROTSTRUC_AMD_NO_AUTOTUNE") or torch.cuda.is_current_stream_capturing():
         return
-    if not pattern and (_lib.get_tuning("k1_flat") == 0 or _lib.get_tuning("k1_variant") != 0):
+    if not pattern and (_lib.get_tuning("k1_flat", device) == 0 or _lib.get_tuning("k1_variant", device) != 0):
         return
-    lib = _lib.load()
-    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_FLAT
+    with _K1_TUNE_LOCK:
+        if result_key in _K1_TUNED.get(device, {}):   # another thread tuned this device while we waited
+            return
+        lib = _lib.load()
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_FLAT
+        fields = ("rows_per_block", "lds_pad_kb") if pattern else ("flat_cpw", "flat_lds_pad_kb")
+        # one private configuration struct per candidate: nothing shared is touched while timing
+        cfgs = {c: _lib.k1_config(device, **dict(zip(fields, c))) for c in candidates}
 
-    def apply(cand):
-        _lib.set_tuning("k1_rows_per_block" if pattern else "k1_flat_cpw", cand[0])
-        _lib.set_tuning("k1_lds_pad_kb" if pattern else "k1_flat_lds_pad_kb", cand[1])
+        def launch(cand):
+            _lib.check(lib.ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfgs[cand]), stream),
+                       "ps_pairwise_distance_cfg_f32 (autotune)")
 
-    def launch(cand):
-        apply(cand)
-        _lib.check(lib.ps_pairwise_distance_f32(*args, stream), "ps_pairwise_distance_f32 (autotune)")
-
-    # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
-    # then time the candidates in interleaved rounds and keep each one's minimum
-    t_end = time.perf_counter() + 0.12
-    while time.perf_counter() < t_end:
-        launch(candidates[0])
-        torch.cuda.current_stream(device).synchronize()
-    timings = {c: float("inf") for c in candidates}
-    for _ in range(3):
-        for c in candidates:
-            launch(c)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            launch(c)
-            launch(c)
-            e1.record()
-            e1.synchronize()
-            timings[c] = min(timings[c], e0.elapsed_time(e1) / 2)
-    best, best_ms = candidates[0], timings[candidates[0]]
-    for c in candidates[1:]:
-        if timings[c] < best_ms * 0.985:   # prefer the earlier (smaller-granule) candidate unless the gain is clear
-            best, best_ms = c, timings[c]
-    apply(best)
-    label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
-    ms = {label[c]: timings[c] for c in candidates}
-    if pattern:
-        _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1], "ms": ms})
-    else:
-        _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best[0], "flat_lds_pad_kb": best[1], "flat_ms": ms})
-
-
-def set_exact_sqrt(flag: bool) -> None:
-    """K1 arithmetic: False (default) = hardware square root, exact for 85 % of inputs and 1 ulp off for the rest;
-    True = correctly rounded square root (slower on devices that are not limited by their store rate).
-    ``PROTSTRUC_AMD_EXACT_SQRT=1`` in the environment selects True at load time."""
-    _lib.set_tuning("k1_exact_sqrt", 1 if flag else 0)
+        # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
+        # then time the candidates in interleaved rounds and keep each one's minimum
+        t_end = time.perf_counter() + 0.12
+        while time.perf_counter() < t_end:
+            launch(candidates[0])
+            torch.cuda.current_stream(device).synchronize()
+        timings = {c: float("inf") for c in candidates}
+        for _ in range(3):
+            for c in candidates:
+                launch(c)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                launch(c)
+                launch(c)
+                e1.record()
+                e1.synchronize()
+                timings[c] = min(timings[c], e0.elapsed_time(e1) / 2)
+        best, best_ms = candidates[0], timings[candidates[0]]
+        for c in candidates[1:]:
+            if timings[c] < best_ms * 0.985:   # prefer the earlier (smaller-granule) candidate unless the gain is clear
+                best, best_ms = c, timings[c]
+        _lib.set_tuning("k1_" + fields[0], best[0], device)
+        _lib.set_tuning("k1_" + fields[1], best[1], device)
+        label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
+        ms = {label[c]: timings[c] for c in candidates}
+        if pattern:
+            _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1], "ms": ms})
+        else:
+            _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best[0], "flat_lds_pad_kb": best[1], "flat_ms": ms})
 
 
-def get_exact_sqrt() -> bool:
-    return bool(_lib.get_tuning("k1_exact_sqrt"))
+def set_exact_sqrt(flag: bool, device=None) -> None:
+    """K1 arithmetic on ``device`` (default: the current one): False (default) = hardware square root, exact for
+    85 % of inputs and 1 ulp off for the rest; True = correctly rounded square root (slower on fast allocations).
+    ``PROTSTRUC_AMD_EXACT_SQRT=1`` in the environment makes True the default of every device."""
+    _lib.set_tuning("k1_exact_sqrt", 1 if flag else 0, device)
+
+
+def get_exact_sqrt(device=None) -> bool:
+    return bool(_lib.get_tuning("k1_exact_sqrt", device))
 
 
 def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,
@@ -247,23 +254,29 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
                 raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
         args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
         _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A)
-        rc = _lib.load().ps_pairwise_distance_f32(*args, _stream(xyz))
-    _lib.check(rc, "ps_pairwise_distance_f32")
+        cfg = _lib.k1_config(xyz.device)   # this device's settings, snapshotted for this launch
+        rc = _lib.load().ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfg), _stream(xyz))
+    _lib.check(rc, "ps_pairwise_distance_cfg_f32")
     return dist, dmask
 
 
-def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask: torch.Tensor):
-    """K2.  Returns (dihedrals (B,N,3) fp32, dihedral_mask (B,N,3) bool, nterm (B,N) bool, cterm (B,N) bool)."""
+def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask: torch.Tensor, *,
+                       want_dihedrals: bool = True, want_mask: bool = True, want_nterm: bool = True,
+                       want_cterm: bool = True):
+    """K2.  Returns (dihedrals (B,N,3) fp32, dihedral_mask (B,N,3) bool, nterm (B,N) bool, cterm (B,N) bool);
+    an output that is not wanted is neither allocated nor written and comes back as None."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     chain = _f32c(chain_idx, "chain_idx")
     rmask = _u8c(residue_mask, "residue_mask")
     dev = xyz.device
+    if not (want_dihedrals or want_mask or want_nterm or want_cterm):
+        raise ValueError("at least one output must be requested")
     with torch.cuda.device(dev):
-        dih = torch.empty(B, N, 3, dtype=torch.float32, device=dev)
-        dmask = torch.empty(B, N, 3, dtype=torch.bool, device=dev)
-        nterm = torch.empty(B, N, dtype=torch.bool, device=dev)
-        cterm = torch.empty(B, N, dtype=torch.bool, device=dev)
+        dih = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_dihedrals else None
+        dmask = torch.empty(B, N, 3, dtype=torch.bool, device=dev) if want_mask else None
+        nterm = torch.empty(B, N, dtype=torch.bool, device=dev) if want_nterm else None
+        cterm = torch.empty(B, N, dtype=torch.bool, device=dev) if want_cterm else None
         rc = _lib.load().ps_backbone_dihedrals_f32(
             _ptr(xyz), _ptr(chain), _ptr(rmask), _ptr(dih), _ptr(dmask), _ptr(nterm), _ptr(cterm), B, N, A,
             _stream(xyz))
@@ -272,8 +285,12 @@ def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask:
 
 
 def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence[int], n_points: int, *,
-                    row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False) -> torch.Tensor:
-    """K3.  n_points = 4: dihedral, 3: planar angle, over points (slots_i of residue i ++ slots_j of residue j)."""
+                    row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K3.  n_points = 4: dihedral, 3: planar angle, over points (slots_i of residue i ++ slots_j of residue j).
+    Only residue rows [row_begin, row_end) are computed, with K1's row addressing: into rows [row_begin, row_end) of
+    a full-size (B, N, N) buffer (``out`` may supply it, e.g. the destination of an all-gather) or, with ``compact``,
+    into a (B, row_end - row_begin, N) buffer."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     slots = [int(s) for s in slots_i] + [int(s) for s in slots_j]
@@ -282,10 +299,15 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
         raise IndexError(f"need {n_points} atoms in total, got {len(slots)}")  # the reference indexes past the end
     slots, src = slots[:n_points], src[:n_points]
     row_end = N if row_end is None else row_end
+    if not (0 <= row_begin <= row_end <= N):
+        raise ValueError(f"row range [{row_begin},{row_end}) outside [0,{N})")
     out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
     arr = ctypes.c_int * n_points
     with torch.cuda.device(xyz.device):
-        out = torch.empty(B, out_rows, N, dtype=torch.float32, device=xyz.device)
+        if out is None:
+            out = torch.empty(B, out_rows, N, dtype=torch.float32, device=xyz.device)
+        else:
+            _check_out(out, (B, out_rows, N), "out", xyz.device)
         rc = _lib.load().ps_pairwise_angles_f32(
             _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
             _stream(xyz))

@@ -212,11 +212,13 @@ class StructureBatch:
     # ------------------------------------------------------------------ A2 terminal masks
     def get_n_terminal_mask(self) -> torch.BoolTensor:
         """True at the first residue of each chain (protstruc.py:435-443)."""
-        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)[2]
+        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask, want_dihedrals=False,
+                                      want_mask=False, want_cterm=False)[2]
 
     def get_c_terminal_mask(self) -> torch.BoolTensor:
         """True at the last residue of each chain (protstruc.py:445-453)."""
-        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)[3]
+        return ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask, want_dihedrals=False,
+                                      want_mask=False, want_nterm=False)[3]
 
     # ------------------------------------------------------------------ A1 pairwise distances
     def pairwise_distance_matrix(self) -> Tuple[torch.FloatTensor, torch.BoolTensor]:
@@ -233,7 +235,8 @@ class StructureBatch:
     # ------------------------------------------------------------------ A3 backbone dihedrals
     def backbone_dihedrals(self) -> Tuple[torch.FloatTensor, torch.BoolTensor]:
         """phi, psi, omega per residue and their validity mask (protstruc.py:486-541)."""
-        dih, dmask, _, _ = ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask)
+        dih, dmask, _, _ = ops.backbone_dihedrals(self.xyz, self.chain_idx, self.residue_mask, want_nterm=False,
+                                                  want_cterm=False)
         return dih, dmask
 
     # ------------------------------------------------------------------ A4 / A5 frames

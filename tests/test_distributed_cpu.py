@@ -23,6 +23,14 @@ def _oracle_rows(xyz, atom_mask=None, *, row_begin=0, row_end=None, out_dist=Non
     return out_dist, out_mask
 
 
+def _oracle_angle_rows(xyz, slots_i, slots_j, n_points, *, row_begin=0, row_end=None, compact=False, out=None):
+    from oracle import protstruc_oracle as O
+    fn = O.pairwise_dihedrals if n_points == 4 else O.pairwise_planar_angles
+    full = fn(xyz, list(slots_i), list(slots_j))
+    out[:, row_begin:row_end] = full[:, row_begin:row_end]
+    return out
+
+
 def _worker(rank, world, port, n_res, gather, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -33,6 +41,7 @@ def _worker(rank, world, port, n_res, gather, q):
         from protstruc_amd import distributed as D
         from protstruc_amd import ops
         ops.pairwise_distance = _oracle_rows
+        ops.pairwise_angles = _oracle_angle_rows
         g = torch.Generator().manual_seed(5)
         xyz = torch.randn(2, n_res, 15, 3, generator=g)
         mask = torch.rand(2, n_res, 15, generator=g) < 0.8
@@ -49,6 +58,17 @@ def _worker(rank, world, port, n_res, gather, q):
             other = torch.ones(n_res, dtype=torch.bool)
             other[lo:hi] = False
             ok = ok and bool(torch.isnan(d[:, other]).all())  # nothing outside the shard was touched
+        # the angle features shard the same way (reference protstruc.py:620-660)
+        for npts, si, sj in ((4, [1, 4], [1, 4]), (3, [1, 4], [4])):
+            buf = torch.full((2, n_res, n_res), 123.0)
+            a, (alo, ahi) = D.pairwise_angles_sharded(xyz, si, sj, npts, gather=gather, out=buf)
+            want = (O.pairwise_dihedrals if npts == 4 else O.pairwise_planar_angles)(xyz, si, sj)
+            same = lambda x, y: torch.equal(x.isnan(), y.isnan()) and torch.equal(x.nan_to_num(9.0), y.nan_to_num(9.0))
+            ok = ok and (alo, ahi) == (lo, hi)
+            if gather:
+                ok = ok and same(a, want)
+            else:
+                ok = ok and same(a[:, lo:hi], want[:, lo:hi]) and bool((a[:, other] == 123.0).all())
         q.put((rank, ok, lo, hi))
     finally:
         dist.destroy_process_group()
@@ -71,6 +91,36 @@ def test_row_sharded_distance_world2(n_res, gather):
         assert all((lo, hi) == (0, n_res) for _, _, lo, hi in got)  # every rank holds all rows, no collective
     else:
         assert got[0][2] == 0 and got[0][3] == got[1][2] and got[1][3] == n_res  # shards tile [0, N)
+
+
+def test_native_shard_rows_matches_python():
+    """ps_shard_rows (the split ps_allgather_rows assumes) is the split the launchers use."""
+    import ctypes
+    from protstruc_amd import _rccl
+    from protstruc_amd.distributed import shard_rows
+    lib = _rccl.load()   # loads RCCL itself; no GPU is touched
+    assert _rccl.rccl_version() > 20000
+    lo, hi = ctypes.c_int(), ctypes.c_int()
+    for n in (1, 7, 8, 229, 512, 2047, 2048, 2 ** 30):
+        for world in (1, 2, 3, 4, 7, 8):
+            for r in range(world):
+                lib.ps_shard_rows(n, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == shard_rows(n, r, world)
+    # argument errors come back before any RCCL call
+    assert lib.ps_allgather_rows(None, None, 1, 8, 64, None) == 1
+    assert lib.ps_comm_create(None, None, 2, 0) == 1
+    assert b"invalid" in lib.ps_comm_error_string(1).lower()
+
+
+def test_rccl_header_matches_binding():
+    import re
+    from protstruc_amd import _rccl
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "protstruc_rccl.h")).read(), flags=re.S)
+    declared = sorted(set(re.findall(r"\b(ps_[a-z0-9_]+)\s*\(", text)))
+    assert declared == sorted(_rccl.SIGNATURES)
+    lib = _rccl.load()
+    for name in declared:
+        assert hasattr(lib, name)
 
 
 def test_shard_rows_partition():

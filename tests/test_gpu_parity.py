@@ -379,6 +379,111 @@ def test_k1_capi_argument_validation_streams_and_capture(SB):
     assert torch.equal(gb[0], eb[0]) and torch.equal(gb[1], eb[1])
 
 
+def test_k1_knobs_flipped_on_another_thread(SB):
+    """The library holds no tuning state: every launch carries a snapshot of its device's host-side table.  One
+    thread rewrites that table as fast as it can while two others launch K1 (pattern and flat-pattern shapes) on
+    their own streams; every result must be the reference bits (all settings compute the same values)."""
+    import threading
+    from protstruc_amd import _lib, ops
+    xa, ma = synth(61, 3, 64)            # N % 16 == 0: pattern kernel
+    xb, mb = synth(62, 2, 50)            # flat pattern kernel
+    xa, ma, xb, mb = xa.cuda(), ma.cuda(), xb.cuda(), mb.cuda()
+    want_a = ops.pairwise_distance(xa, ma)
+    want_b = ops.pairwise_distance(xb, mb)
+    torch.cuda.synchronize()
+    keys = ("k1_rows_per_block", "k1_jt", "k1_flat_cpw", "k1_xcd_remap", "k1_store_nt", "k1_lds_pad_kb", "k1_flat")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    stop = threading.Event()
+    errors = []
+
+    def flipper():
+        rng = np.random.default_rng(5)
+        while not stop.is_set():
+            _lib.set_tuning("k1_rows_per_block", int(rng.choice([1, 2, 3, 4, 8])))
+            _lib.set_tuning("k1_jt", int(rng.choice([0, 64, 128])))
+            _lib.set_tuning("k1_flat_cpw", int(rng.choice([1, 2, 5])))
+            _lib.set_tuning("k1_xcd_remap", int(rng.integers(0, 2)))
+            _lib.set_tuning("k1_store_nt", int(rng.integers(0, 2)))
+            _lib.set_tuning("k1_lds_pad_kb", int(rng.choice([0, 8])))
+            _lib.set_tuning("k1_flat", int(rng.choice([1, 2])))
+
+    def launcher(x, m, want):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(150):
+                    d, k = ops.pairwise_distance(x, m)
+                    st.synchronize()
+                    if not (torch.equal(d, want[0]) and torch.equal(k, want[1])):
+                        errors.append("bits differ")
+                        return
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=flipper), threading.Thread(target=launcher, args=(xa, ma, want_a)),
+               threading.Thread(target=launcher, args=(xb, mb, want_b))]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads[1:]:
+            t.join()
+    finally:
+        stop.set()
+        threads[0].join()
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+    assert not errors, errors
+    # another device's entry was never touched by any of this
+    assert _lib.get_tuning("k1_rows_per_block", device=7) == 1
+
+
+def test_k1_explicit_config_through_the_c_abi(SB):
+    """ps_pairwise_distance_cfg_f32 called directly with caller-built structs: every valid configuration gives the
+    bits of the default call, malformed ones return hipErrorInvalidValue and write nothing."""
+    import ctypes
+    from protstruc_amd import _lib
+    lib = _lib.load()
+    xyz, mask = synth(63, 2, 48)
+    xg, mg = xyz.cuda(), mask.cuda().view(torch.uint8)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(cfg):
+        d = torch.full((2, 48, 48, 15, 15), -3.0, device="cuda")
+        m = torch.full((2, 48, 48, 15, 15), 9, dtype=torch.uint8, device="cuda")
+        rc = lib.ps_pairwise_distance_cfg_f32(P(xg), P(mg), P(d), P(m), 2, 48, 15, 0, 48, 48, 0,
+                                              None if cfg is None else ctypes.byref(cfg), st)
+        torch.cuda.synchronize()
+        return rc, d, m
+
+    rc, ref_d, ref_m = run(None)
+    assert rc == 0 and (ref_m <= 1).all() and not (ref_d == -3.0).any()
+    default = _lib.K1Config()
+    lib.ps_k1_config_default(ctypes.byref(default))
+    for over in [{}, {"rows_per_block": 4}, {"jt": 64, "rows_per_block": 3}, {"variant": 1}, {"flat": 2, "flat_cpw": 3},
+                 {"flat": 3}, {"flat": 0}, {"xcd_remap": 0, "store_nt": 1}, {"lds_pad_kb": 8}]:
+        cfg = _lib.K1Config(**{**{f: getattr(default, f) for f, _ in _lib.K1Config._fields_}, **over})
+        rc, d, m = run(cfg)
+        assert rc == 0 and torch.equal(d, ref_d) and torch.equal(m, ref_m), over
+    for over in [{"struct_size": 4}, {"experiment": 2}, {"rows_per_block": 0}, {"flat": 9}]:
+        cfg = _lib.K1Config(**{**{f: getattr(default, f) for f, _ in _lib.K1Config._fields_}, **over})
+        rc, d, m = run(cfg)
+        assert rc == 1 and (d == -3.0).all() and (m == 9).all(), over
+
+
+def test_terminal_masks_request_only_their_output(SB):
+    from protstruc_amd import ops
+    g = load_golden("g2_bbdih_chains")
+    sb = SB.from_xyz(g["xyz"], g["atom_mask"], g["chain_idx"], chain_ids=[["A", "B", "C"]] * g["xyz"].shape[0])
+    assert torch.equal(sb.get_n_terminal_mask().cpu(), g["nterm"]) and torch.equal(sb.get_c_terminal_mask().cpu(), g["cterm"])
+    only = ops.backbone_dihedrals(sb.xyz, sb.chain_idx, sb.residue_mask, want_dihedrals=False, want_mask=False,
+                                  want_nterm=False)
+    assert only[0] is None and only[1] is None and only[2] is None and torch.equal(only[3].cpu(), g["cterm"])
+    with pytest.raises(ValueError):
+        ops.backbone_dihedrals(sb.xyz, sb.chain_idx, sb.residue_mask, want_dihedrals=False, want_mask=False,
+                               want_nterm=False, want_cterm=False)
+
+
 def test_k1_allocate_fast_outputs(SB):
     """The allocation-shopping helper returns usable buffers and a report; results do not depend on the choice."""
     from protstruc_amd import ops

@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""K1 experiments: where is the time going?  math modes x tile x rows, interleaved rounds."""
+"""K1 experiments: where is the time going?  math modes x tile x rows, interleaved rounds.
+Needs the experiments build (store-only mode writes WRONG values and is not compiled into the product library):
+    python -m protstruc_amd.build --experiments
+    PROTSTRUC_AMD_LIB=protstruc_amd/lib/libprotstruc_hip_experiments.so python tools/k1_probe2.py
+m = 0: correctly rounded sqrt, 1: hardware sqrt (product default), 2: store-only."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os
@@ -19,7 +23,7 @@ res = {}
 variants = [(m, jt, rows) for m in (0, 1, 2) for jt in (64, 128) for rows in (1, 2)]
 for rnd in range(3):
     for m, jt, rows in variants:
-        _lib.set_tuning("k1_math", m); _lib.set_tuning("k1_jt", jt); _lib.set_tuning("k1_rows_per_block", rows)
+        _lib.set_tuning("k1_exact_sqrt", int(m == 0)); _lib.set_tuning("k1_experiment", 2 if m == 2 else 0); _lib.set_tuning("k1_jt", jt); _lib.set_tuning("k1_rows_per_block", rows)
         for what in ("both", "dist", "mask"):
             if what == "mask" and m: continue
             wd, wm = what != "mask", what != "dist"
