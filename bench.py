@@ -152,10 +152,14 @@ def check_outputs(xyz, mask, out_d, out_m, n_blocks=64, seed=7):
     if not torch.equal(out_m[bs, i_s, js], want_m):
         fails.append("sampled mask blocks differ")
     # exact checksum of the whole mask plane, per structure: sum = (number of present atoms)^2
+    # (count_nonzero per structure: a sum with dtype=int64 would first cast the whole 1-byte plane to 8-byte words)
     count = mask.sum((1, 2), dtype=torch.int64)
-    got_sum = out_m.view(torch.uint8).sum((1, 2, 3, 4), dtype=torch.int64)
+    bytes_ = out_m.view(torch.uint8)
+    got_sum = torch.stack([torch.count_nonzero(bytes_[b]) for b in range(b_)])
     if not torch.equal(got_sum, count * count):
         fails.append("mask checksum per structure differs from (present atoms)^2")
+    if int(bytes_.max()) > 1:
+        fails.append("mask plane holds bytes other than 0 / 1")
     # symmetry of one whole structure: d[i,j,a,c] == d[j,i,c,a] bit for bit
     bsym = int(bs[0])
     if not torch.equal(out_d[bsym], out_d[bsym].permute(1, 0, 3, 2)):

@@ -39,21 +39,24 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     for (int k = 0; k < NP; ++k) pj[k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
 
     int i = i0;
-    if constexpr (NP == 4) {
-        // two rows per trip in the two halves of float2 registers -> packed v_pk_* math (bit-identical per element)
-        for (; i + 1 < i1; i += 2) {
-            const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
-            const float* s1 = s0 + (size_t)A * 3;
-            f3v p[4];
+    // two rows per trip in the two halves of float2 registers -> packed v_pk_* math (bit-identical per element);
+    // dihedrals and planar angles alike
+    for (; i + 1 < i1; i += 2) {
+        const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
+        const float* s1 = s0 + (size_t)A * 3;
+        f3v p[NP];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                p[k] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(s0 + sel.atom[k] * 3), load3(s1 + sel.atom[k] * 3));
-            const f32x2 v = dihedral4v(p[0], p[1], p[2], p[3]);
-            if (live) {
-                float* o = out + ((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j;
-                o[0] = v.x;
-                o[N] = v.y;
-            }
+        for (int k = 0; k < NP; ++k)
+            p[k] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(s0 + sel.atom[k] * 3), load3(s1 + sel.atom[k] * 3));
+        f32x2 v;
+        if constexpr (NP == 4)
+            v = dihedral4v(p[0], p[1], p[2], p[3]);
+        else
+            v = angle3v(p[0], p[1], p[2]);
+        if (live) {
+            float* o = out + ((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j;
+            o[0] = v.x;
+            o[N] = v.y;
         }
     }
     for (; i < i1; ++i) {
@@ -109,18 +112,26 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         phi[o] = angle3(ca_i, cb_i, cb_j);
     };
     int i = i0;
-    for (; i + 1 < i1; i += 2) {  // two rows per trip: the two dihedrals run as packed float2 math
+    for (; i + 1 < i1; i += 2) {  // two rows per trip: distances, planar angle and both dihedrals as packed float2 math
         f3 n0, ca0, cb0, n1, ca1, cb1;
         uint8_t a0, b0, c0, a1, b1, c1;
         row_scalars(i, n0, ca0, cb0, a0, b0, c0);
         row_scalars(i + 1, n1, ca1, cb1, a1, b1, c1);
         if (!live) continue;
         const size_t o = ((size_t)b * N + i) * N + j;
-        row_planes(o, n0, ca0, cb0, a0, b0, c0);
-        row_planes(o + N, n1, ca1, cb1, a1, b1, c1);
-        const f3v cav = mk3v(ca0, ca1), cbv = mk3v(cb0, cb1), nv = mk3v(n0, n1), cajv = mk3v(ca_j, ca_j), cbjv = mk3v(cb_j, cb_j);
+        const f3v cav = mk3v(ca0, ca1), cbv = mk3v(cb0, cb1), nv = mk3v(n0, n1);
+        const f3v cajv = mk3v(ca_j, ca_j), cbjv = mk3v(cb_j, cb_j), ojv = mk3v(o_j, o_j);
+        const f32x2 dca = dist3v(cav, cajv), dcb = dist3v(cbv, cbjv), dno = dist3v(nv, ojv);
+        const f32x2 ph = angle3v(cav, cbv, cbjv);
         const f32x2 om = dihedral4v(cav, cbv, cajv, cbjv);   // as coded at protstruc.py:811
         const f32x2 th = dihedral4v(nv, cav, cbv, cbjv);
+        d_ca[o] = dca.x; d_ca[o + N] = dca.y;
+        d_cb[o] = dcb.x; d_cb[o + N] = dcb.y;
+        d_no[o] = dno.x; d_no[o + N] = dno.y;
+        m_ca[o] = b0 & mj_ca; m_ca[o + N] = b1 & mj_ca;
+        m_cb[o] = c0 & mj_cb; m_cb[o + N] = c1 & mj_cb;
+        m_no[o] = a0 & mj_o;  m_no[o + N] = a1 & mj_o;
+        phi[o] = ph.x; phi[o + N] = ph.y;
         omega[o] = om.x; omega[o + N] = om.y;
         theta[o] = th.x; theta[o + N] = th.y;
     }

@@ -29,6 +29,8 @@
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int A15 = 15;
@@ -687,6 +689,280 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
     }
 }
 
+// ---- fixed-A flat pattern kernel (compile-time atom count, any N >= 16, 16-byte aligned planes) ----
+// The A = 15 flat pattern kernel generalised to a compile-time atom count A with A*A >= 129 (12 <= A <= 64): atom14
+// and atom37 are the layouts real pipelines use next to the reference's 15 slots (`from_xyz` accepts any A,
+// protstruc.py:94-128, tests/test_StructureBatch.py:11-21).  Four consecutive pairs are A*A float4 slots and sixteen
+// consecutive pairs are A*A 16-byte mask slots for EVERY A (a pair is A*A elements and the planes start 16-byte
+// aligned), so the fixed-lane pattern carries over: slot s of a group always decodes to the same (pair offset, a, c).
+// What changes with A:
+//   * A*A can exceed the 256 lanes: lane t owns slots t, t + 256, ... (SPL = ceil(A*A / 256) per group; atom37: 6).
+//     The sweep takes one slot set at a time (u outer, the chunk's groups inner), so only ONE slot's pattern -- four
+//     column-atom offsets, four row atoms -- is live in registers whatever SPL is (the first cut kept all six and
+//     spilled 247 VGPRs);
+//   * staging deals LPR = next power of two >= A lanes to a residue, and a residue's LDS image is RS float4 slots:
+//     16 for A <= 16 (atoms of one residue on distinct banks), A for larger A with the atom order permuted by the
+//     inverse of 4 mod A, so that the 16 lanes of a service group -- whose atoms are 4 apart -- read consecutive
+//     LDS slots instead of slots 64 bytes * k apart (bank conflicts);
+//   * mask rows are A bits wide: a 16-byte mask slot spans up to 2 + 14/A rows; words are 64-bit when A > 32.
+// Bit-identical to the element-per-lane kernel and to the any-A flat kernel (tests/test_gpu_k1_fuzz.py).
+template <int A>
+struct FlatA {
+    static_assert(A >= 12 && A <= 64, "fixed-A flat kernel: 12 <= A <= 64");
+    static constexpr int AA = A * A;
+    static constexpr int LPR = A <= 16 ? 16 : (A <= 32 ? 32 : 64);       // lanes per staged residue
+    static constexpr int RPP = 256 / LPR;                                 // residues staged per pass
+    static constexpr int RS = A <= 16 ? 16 : A;                           // float4 slots per staged residue
+    static constexpr int SPL = (AA + 255) / 256;                          // slots per lane per group
+    static constexpr int FL_LOG2 = A <= 16 ? 7 : (A <= 24 ? 6 : (A <= 40 ? 5 : 4));
+    static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
+    static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
+    static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;              // row residues staged per chunk
+    static constexpr int MROWS = 2 + 14 / A;                              // mask rows a 16-byte slot can span
+    static constexpr unsigned minv() {                                    // 4 * minv = 1 (mod A) for odd A > 16
+        if (A <= 16 || A % 2 == 0) return 1u;
+        for (unsigned m = 1; m < (unsigned)A; ++m)
+            if ((4u * m) % (unsigned)A == 1u) return m;
+        return 1u;
+    }
+    typedef typename std::conditional<(A > 32), unsigned long long, uint32_t>::type mask_t;
+};
+
+template <int A>
+__device__ __forceinline__ unsigned swz_atom(unsigned c) {
+    return FlatA<A>::minv() == 1u ? c : (c * FlatA<A>::minv()) % (unsigned)A;
+}
+
+template <int A, bool EXACT, bool HASMASK>
+__global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restrict__ xyz,
+                                                           const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                           int B, int N, int out_rows, int out_row_origin,
+                                                           unsigned pbeg, unsigned pend, unsigned n_ranges,
+                                                           unsigned range_stride, unsigned cpr, int cpw,
+                                                           int xcd_remap, double rcpN_d, double rcpR_d) {
+    using G = FlatA<A>;
+    constexpr int AA = G::AA, RSn = G::RS, FLn = G::FLn, FRn = G::FRn, LPR = G::LPR, RPP = G::RPP, SPL = G::SPL;
+    constexpr int NPASS = FLn / RPP, RPASS = FRn / RPP;
+    typedef typename G::mask_t mask_t;
+    __shared__ __attribute__((aligned(16))) float4 sxj[FLn * RSn];
+    __shared__ __attribute__((aligned(16))) float4 sxi[FRn * RSn];
+    __shared__ mask_t smj[FLn], smi[FRn], smr[FLn];   // column bits / row bits per staged residue; row bits per pair position
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned n = gridDim.x, x = w & 7u;
+        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
+    }
+    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
+    const int pl = tid / LPR, cl = tid % LPR;          // staging: LPR lanes per residue
+    const unsigned cs = (cl < A) ? swz_atom<A>((unsigned)cl) : (unsigned)cl;   // LDS slot of this lane's atom
+    const mask_t abits = (A >= 64) ? ~(mask_t)0 : (((mask_t)1 << (A & 63)) - 1);
+
+    const unsigned n_chunks = n_ranges * cpr;
+    for (int cc = 0; cc < cpw; ++cc) {
+        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
+        if (chunk >= n_chunks) break;  // uniform
+        if (cc) __syncthreads();
+        unsigned rg = 0, k = chunk;
+        if (n_ranges > 1) {
+            rg = chunk / cpr;
+            k = chunk - rg * cpr;
+        }
+        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
+        const unsigned P0 = ((rbeg >> G::FL_LOG2) + k) << G::FL_LOG2;
+        if (P0 >= rend) continue;  // uniform
+        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
+        const int hi = rend - P0 < (unsigned)FLn ? (int)(rend - P0) : FLn;
+        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
+        if (R0 * (unsigned long long)N > P0) --R0;
+        else if ((R0 + 1ull) * N <= P0) ++R0;
+        const int j_start = (int)(P0 - R0 * (unsigned)N);
+        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
+        if (b0 * (unsigned long long)out_rows > R0) --b0;
+        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
+        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
+        const int nr = (j_start + FLn - 1) / N + 1;  // rows the chunk touches (<= G::NR)
+
+        // ---- stage (all global loads before the first LDS write; (row, column, structure) walked, not divided) ----
+        float vx[NPASS + RPASS], vy[NPASS + RPASS], vz[NPASS + RPASS];
+        unsigned vm[NPASS + RPASS];
+        bool va[NPASS + RPASS];
+        {
+            unsigned rl = udiv_rcp((unsigned)(j_start + pl), (unsigned)N, rcpN);
+            unsigned j = (unsigned)(j_start + pl) - rl * (unsigned)N;
+            const unsigned db = udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
+            unsigned il = il0 + rl - db * (unsigned)out_rows;
+            unsigned res0 = (b0 + db) * (unsigned)N;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int p = pass * RPP + pl;
+                va[pass] = (p >= lo) && (p < hi) && (cl < A);
+                const unsigned src = va[pass] ? (res0 + j) * A + cl : 0u;
+                vx[pass] = xyz[src * 3u + 0];
+                vy[pass] = xyz[src * 3u + 1];
+                vz[pass] = xyz[src * 3u + 2];
+                vm[pass] = HASMASK ? (unsigned)amask[src] : 1u;
+                j += RPP;                      // RPP <= 16 <= N: at most one row change per pass
+                if (j >= (unsigned)N) {
+                    j -= (unsigned)N;
+                    if (++il == (unsigned)out_rows) {
+                        il = 0;
+                        res0 += (unsigned)N;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rp = 0; rp < RPASS; ++rp) {
+            const unsigned rr = (unsigned)(rp * RPP + pl);
+            const unsigned ilr = il0 + rr;
+            const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
+            const unsigned bb = b0 + db;
+            const unsigned i = ilr - db * (unsigned)out_rows + (unsigned)out_row_origin;
+            const int L = NPASS + rp;
+            va[L] = ((int)rr < nr) && (bb < (unsigned)B) && (cl < A);
+            const unsigned src = va[L] ? (bb * (unsigned)N + i) * A + cl : 0u;
+            vx[L] = xyz[src * 3u + 0];
+            vy[L] = xyz[src * 3u + 1];
+            vz[L] = xyz[src * 3u + 2];
+            vm[L] = HASMASK ? (unsigned)amask[src] : 1u;
+        }
+        constexpr int FIELDS = 64 / LPR;   // residues per wave
+#pragma unroll
+        for (int pass = 0; pass < NPASS + RPASS; ++pass) {
+            const bool is_row = pass >= NPASS;
+            const int p = (is_row ? pass - NPASS : pass) * RPP + pl;
+            if (cl < RSn)
+                (is_row ? sxi : sxj)[p * RSn + cs] =
+                    va[pass] ? make_float4(vx[pass], vy[pass], vz[pass], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned long long bal = __ballot(va[pass] && vm[pass] != 0u);
+            if (cl == 0) (is_row ? smi : smj)[p] = (mask_t)(bal >> (LPR * (pl % FIELDS))) & abits;
+        }
+        __syncthreads();
+        if (dmask && tid < FLn) {
+            const unsigned rl = udiv_rcp((unsigned)(j_start + tid), (unsigned)N, rcpN);
+            smr[tid] = (tid >= lo && tid < hi) ? smi[rl] : (mask_t)0;   // smj is already 0 outside [lo, hi)
+        }
+        __syncthreads();
+
+        if (dist) {
+            // One slot set at a time (u outer, groups inner): only one slot's pattern -- four column-atom offsets and
+            // four row atoms -- is live in registers, whatever SPL is.  A wave's store is still 1 KB contiguous.
+#pragma unroll 1
+            for (int u = 0; u < SPL; ++u) {
+                const unsigned sl = (unsigned)tid + 256u * (unsigned)u;   // slot inside a 4-pair group
+                if (sl >= (unsigned)AA) break;
+                unsigned offj[4], ai[4], jo[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    const unsigned e = 4u * sl + kk;
+                    jo[kk] = e / AA;
+                    const unsigned r = e - jo[kk] * AA;
+                    const unsigned a = r / A, c = r - a * A;
+                    offj[kk] = jo[kk] * RSn + swz_atom<A>(c);
+                    ai[kk] = swz_atom<A>(a);
+                }
+                float* o = dist + (size_t)P0 * AA + 4u * sl;
+                int rl = 0;                // row of pair 4g
+                int nb = N - j_start;      // pair position where row rl + 1 starts
+                int g = 0;
+                while (g < FLn / 4) {
+                    const int p = 4 * g;
+                    if (p >= hi) break;
+                    while (nb <= p) {
+                        ++rl;
+                        nb += N;
+                    }
+                    const int pe = min(nb, hi);
+                    const int nfast = (p >= lo) ? (pe - p) >> 2 : 0;
+                    if (nfast > 0) {  // whole groups inside one row and inside the active range
+                        float4 pi[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pi[kk] = sxi[rl * RSn + ai[kk]];
+#pragma unroll 4
+                        for (int q = 0; q < nfast; ++q) {
+                            const float4* x = sxj + (g + q) * (4 * RSn);
+                            const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
+                            const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
+                            uint4 v;
+                            v.x = __float_as_uint(dist_pp<EXACT>(pi[0], q0));
+                            v.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
+                            v.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
+                            v.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
+                            store16<false>(o + (size_t)(g + q) * (4 * AA), v);
+                        }
+                        g += nfast;
+                        continue;
+                    }
+                    if (p + 4 > lo) {  // straddles a row change or the edge of the active range: element-wise
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            const int pp = p + (int)jo[kk];
+                            if (pp >= lo && pp < hi) {
+                                const int rk = rl + (pp >= nb ? 1 : 0);  // N >= 16: at most one row change per group
+                                const float4 xi = sxi[rk * RSn + ai[kk]];
+                                const float4 xq = sxj[g * (4 * RSn) + offj[kk]];
+                                o[(size_t)g * (4 * AA) + kk] = dist_pp<EXACT>(xi, xq);
+                            }
+                        }
+                    }
+                    ++g;
+                }
+            }
+        }
+
+        if (dmask) {
+            constexpr int MR = G::MROWS;
+#pragma unroll 1
+            for (int u = 0; u < SPL; ++u) {
+                if ((unsigned)tid + 256u * (unsigned)u >= (unsigned)AA) break;
+                const unsigned e0 = 16u * ((unsigned)tid + 256u * (unsigned)u);  // byte inside a 16-pair group
+                const unsigned jo = e0 / AA, r = e0 - jo * AA;
+                const unsigned a = r / A, c = r - a * A;
+                unsigned prow[MR], arow[MR];
+                int sh[MR];   // bit position of row m's first bit inside the 16-bit window (negative: starts before it)
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const unsigned am = a + m;
+                    const bool wp = am >= (unsigned)A;
+                    prow[m] = min(jo + (wp ? 1u : 0u), 15u);   // rows with sh >= 16 contribute nothing (index clamped)
+                    arow[m] = wp ? am - A : am;
+                    sh[m] = m * A - (int)c;
+                }
+                uint8_t* o = dmask + (size_t)P0 * AA + e0;
+#pragma unroll 1   // unrolled, the eight groups' row words stay live at once and the kernel spills
+                for (int mg = 0; mg < FLn / 16; ++mg) {
+                    const int pg = 16 * mg;
+                    if (pg < hi && pg + 16 > lo) {
+                        uint32_t win = 0;
+#pragma unroll
+                        for (int m = 0; m < MR; ++m) {
+                            if (sh[m] < 16) {
+                                const mask_t col = smj[pg + prow[m]], row = smr[pg + prow[m]];
+                                const mask_t bits = ((row >> arow[m]) & 1) ? col : (mask_t)0;
+                                win |= sh[m] <= 0 ? (uint32_t)(bits >> (-sh[m])) : ((uint32_t)bits << sh[m]);
+                            }
+                        }
+                        win &= 0xFFFFu;
+                        uint8_t* og = o + (size_t)mg * (16 * AA);
+                        if (pg >= lo && pg + 16 <= hi) {
+                            store16<false>(og, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
+                                                          spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
+                        } else {
+                            for (unsigned t = 0; t < 16u; ++t) {
+                                const int pp = pg + (int)jo + ((r + t >= (unsigned)AA) ? 1 : 0);
+                                if (pp >= lo && pp < hi) og[t] = (uint8_t)((win >> t) & 1u);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
 // Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
 // fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
@@ -1010,6 +1286,43 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
 #undef PS_K1_FLAT
 }
 
+// Fixed-A flat pattern kernel: instantiated for the atom counts real pipelines use next to 15 (atom14, atom37), for
+// 25 (the atom count of the reference's own from_xyz test, tests/test_StructureBatch.py:11-21) and 16;
+// A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
+// kernel (cfg.flat == 4).  Other atom counts take the any-A flat kernel.
+bool flatA_has(int A) { return A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
+
+bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
+    if (g.variant != 0 || g.flat == 0 || g.flat == 3 || !flatA_has(A)) return false;
+    if (A == 15 && g.flat != 4) return false;   // A = 15 has its own kernels
+    if (N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
+    if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;      // pair indices stay 32-bit
+    if ((unsigned long long)B * N * A * 3 >= 0x80000000ull) return false;        // and so do coordinate indices
+    if ((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15)) return false;
+    return true;
+}
+
+template <int A>
+int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
+                 int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
+                 unsigned range_stride, hipStream_t s) {
+    if (pbeg >= pend || n_ranges == 0) return 0;
+    constexpr int L2 = FlatA<A>::FL_LOG2, FLn = FlatA<A>::FLn;
+    const unsigned cpr = n_ranges == 1 ? ((pend + (FLn - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
+    const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
+    if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g.flat_cpw : 1u;
+    const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
+    const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
+#define PS_K1_FLATA(EX_, HM_)                                                                                     \
+    ps_launch(k1_pairdist_flatA<A, EX_, HM_>, dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N,         \
+              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
+    if (g.exact_sqrt) return amask ? PS_K1_FLATA(true, true) : PS_K1_FLATA(true, false);
+    return amask ? PS_K1_FLATA(false, true) : PS_K1_FLATA(false, false);
+#undef PS_K1_FLATA
+}
+
 // Any-A flat kernel: chunk length (a power of two, >= 16 pairs) so that the LDS image stays near 40 KB.
 bool anyA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
     if (g.variant != 0 || g.flat == 0) return false;
@@ -1098,6 +1411,21 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
+    if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
+        // one contiguous pair range when every output row is computed, else the same rows of every structure
+        const bool whole = rows == out_rows;
+        const unsigned r0 = whole ? 0u : (unsigned)(row_begin - out_row_origin) * (unsigned)N;
+        const unsigned r1 = whole ? (unsigned)((unsigned long long)B * out_rows * N) : r0 + (unsigned)rows * (unsigned)N;
+        const unsigned nrg = whole ? 1u : (unsigned)B, stride = whole ? 0u : (unsigned)out_rows * (unsigned)N;
+        switch (A) {
+            case 14: return launch_flatA<14>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 25: return launch_flatA<25>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 37: return launch_flatA<37>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            default: break;
+        }
+    }
     if ((A != A15 || g.flat == 3) && anyA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         if (rows == out_rows)
             return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,

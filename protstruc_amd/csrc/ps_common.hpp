@@ -164,6 +164,34 @@ __device__ __forceinline__ f32x2 dihedral4v(f3v a, f3v b, f3v c, f3v d) {
     return f32x2{atan2_ps(ym.x * __builtin_amdgcn_rsqf(nn.x), x.x), atan2_ps(ym.y * __builtin_amdgcn_rsqf(nn.y), x.y)};
 }
 
+// sqrt_rn_mk on both halves: v_rsq_f32 and the class test per element, the Newton / residual steps as packed fma
+// (element for element the operations of the scalar routine, hence the same bits)
+__device__ __forceinline__ f32x2 sqrt_rn_mk_v(f32x2 x) {
+    const f32x2 y = {__builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y)};
+    f32x2 g = x * y;
+    f32x2 h = f32x2{0.5f, 0.5f} * y;
+    const f32x2 r = __builtin_elementwise_fma(-h, g, f32x2{0.5f, 0.5f});
+    g = __builtin_elementwise_fma(g, r, g);
+    h = __builtin_elementwise_fma(h, r, h);
+    const f32x2 d = __builtin_elementwise_fma(-g, g, x);
+    g = __builtin_elementwise_fma(d, h, g);
+    return f32x2{__builtin_amdgcn_classf(x.x, 0x2F0) ? x.x : g.x, __builtin_amdgcn_classf(x.y, 0x2F0) ? x.y : g.y};
+}
+
+// dist3 / angle3 for two problems per lane (same operations in the same order as the scalar functions below / above)
+__device__ __forceinline__ f32x2 dist3v(f3v a, f3v b) {
+    const f32x2 dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const f32x2 sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    return sqrt_rn_mk_v((sx + sy) + sz);
+}
+
+__device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
+    const f3v ba = sub3v(a, b), bc = sub3v(c, b);
+    const f32x2 num = dot3v(ba, bc);
+    const f32x2 den = sqrt_rn_mk_v(dot3v(ba, ba)) * sqrt_rn_mk_v(dot3v(bc, bc));
+    return f32x2{acosf(num.x / den.x), acosf(num.y / den.y)};
+}
+
 // geometry.angle (geometry.py:64-71): no clamp before acos
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     f3 ba = sub3(a, b);

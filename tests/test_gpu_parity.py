@@ -200,18 +200,22 @@ def _same_floats(a, b):
 
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
-    """The vectorised any-A flat kernel against the element-per-lane kernel (k1_flat=0) for atom counts other than
-    15 -- and against the pattern kernels at A = 15 (k1_flat=3) -- over full, compact and in-place row ranges, with
-    sentinel guards around every output."""
+    """The vectorised any-A flat kernel (k1_flat=3) and the fixed-A flat pattern kernel (k1_flat=4; A in 14, 15, 37)
+    against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
+    at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
     keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
     saved = {k: _lib.get_tuning(k) for k in keys}
     _lib.set_tuning("k1_exact_sqrt", exact)
     SENT = 12345.0
     cases = [(2, 16, 1), (3, 17, 2), (2, 33, 3), (3, 50, 4), (2, 100, 5), (2, 37, 14), (2, 64, 16), (2, 21, 25),
-             (1, 40, 37), (1, 19, 64), (2, 250, 4), (2, 37, 15), (1, 128, 15)]
+             (1, 40, 37), (1, 19, 64), (2, 250, 4), (2, 37, 15), (1, 128, 15),
+             # the fixed-A flat pattern kernel (atom14 / atom37, and A = 15 as the template's cross-check): shapes that
+             # cross rows inside a 4-pair group, chunks that span several rows and structures, N = 16 (shortest)
+             (2, 16, 14), (3, 300, 14), (2, 129, 14), (1, 16, 37), (2, 17, 37), (2, 130, 37), (2, 200, 15), (3, 19, 15),
+             (2, 90, 16), (2, 70, 25), (1, 16, 25)]
     try:
-        for (B, N, A) in cases:
+        for (B, N, A), flat in [(c, f) for c in cases for f in ((3, 4) if c[2] in (14, 15, 16, 25, 37) else (3,))]:
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
@@ -221,7 +225,7 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
             ref_d0, _ = ops.pairwise_distance(xg, None)
             rd, rm = O.pairwise_distance_matrix(xyz, mask)
             assert_close(ref_d, rd)
-            _lib.set_tuning("k1_flat", 3)
+            _lib.set_tuning("k1_flat", flat)
             numel = ref_d.numel()
             for cpw, nt in [(1, 0), (3, 1)]:
                 _lib.set_tuning("k1_flat_cpw", cpw)
@@ -232,8 +236,8 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
                 d = bd[pad:pad + numel].view(ref_d.shape)
                 m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
                 ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
-                assert _same_floats(d, ref_d), (B, N, A, cpw)
-                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw)
+                assert _same_floats(d, ref_d), (B, N, A, cpw, flat)
+                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat)
                 assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
                 assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
                 d0, _ = ops.pairwise_distance(xg, None, want_mask=False)
@@ -1257,6 +1261,30 @@ def test_config1_from_pdb_15c8(SB):
     multi = SB.from_pdb([os.path.join(GOLDEN_DIR, n) for n in ("15c8_HL.pdb", "1ad0_DC.pdb", "6dc4.pdb")])
     assert len(multi.get_xyz()) == 3
     assert (multi.get_n_terminal_mask().sum(1) == 2).all() and (multi.get_c_terminal_mask().sum(1) == 2).all()
+
+
+def test_from_pdb_termini(SB):
+    """reference tests/test_StructureBatch.py:43-66 on the GPU path: from_pdb (single, then the reference's three
+    files plus its other fixtures, padded to 448 residues incl. the 7 UNK fillers of 5cjx_HL) -> two N- and two
+    C-termini per structure; masks and dihedrals equal the oracle on the reader's tensors."""
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sb1 = SB.from_pdb(os.path.join(G, "1ad0_DC.pdb"))
+    assert len(sb1.get_xyz()) == 1
+    assert (sb1.get_n_terminal_mask().sum(axis=1) == 2).all() and (sb1.get_c_terminal_mask().sum(axis=1) == 2).all()
+    names = ["15c8_HL.pdb", "1ad0_DC.pdb", "5cjx_HL.pdb", "1a3r_HL.pdb", "1a6v_HL.pdb", "1a6v_JN.pdb"]
+    sb = SB.from_pdb([os.path.join(G, n) for n in names])
+    assert len(sb.get_xyz()) == 6 and sb.get_max_n_residues() == 448
+    nterm, cterm = sb.get_n_terminal_mask(), sb.get_c_terminal_mask()
+    assert (nterm.sum(axis=1) == 2).all() and (cterm.sum(axis=1) == 2).all()
+    chain, rmask = sb.chain_idx.cpu(), sb.residue_mask.cpu()
+    assert torch.equal(nterm.cpu(), O.n_terminal_mask(chain, rmask)) and torch.equal(cterm.cpu(), O.c_terminal_mask(chain, rmask))
+    dih, dmask = sb.backbone_dihedrals()
+    want, wmask = O.backbone_dihedrals(sb.get_xyz().cpu(), chain, rmask)
+    assert torch.equal(dmask.cpu(), wmask)
+    valid = wmask & ~torch.isnan(want)
+    assert ((dih.cpu() - want).abs()[valid] <= 1e-5).all()
+    assert torch.equal(torch.isnan(dih.cpu()), torch.isnan(want))
 
 
 def test_geometry_free_functions(SB):

@@ -15,6 +15,10 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     ("15c8_HL.pdb", 229, ["L", "H"], 0),      # reference tests/test_geometry.py:214 (L = 229)
     ("6dc4.pdb", 437, ["H", "L"], 0),         # reference tests/test_AntibodyStructureBatch.py:13
     ("1ad0_DC.pdb", 434, ["C", "D"], 1),      # one numbering gap -> one UNK filler
+    ("5cjx_HL.pdb", 448, ["H", "L"], 7),      # the hardest fixture: a 1-residue and a 6-residue gap in chain H
+    ("1a3r_HL.pdb", 232, ["L", "H"], 0),
+    ("1a6v_HL.pdb", 229, ["L", "H"], 1),
+    ("1a6v_JN.pdb", 230, ["L", "H"], 1),
 ])
 def test_residue_counts(name, n_res, chains, n_unk):
     p = PDB.read_pdb(os.path.join(G, name))
@@ -86,3 +90,43 @@ def test_seq_idx_from_pdb():
     assert idx[0, 0] == 2                      # ASP -> D -> 2 (reference general.py:126-133)
     assert (idx[0, 229:] == 20).all()          # padding is UNK
     assert idx.max() <= 20 and idx.min() >= 0
+
+
+def test_gap_fill_and_insertion_codes_of_5cjx():
+    """reference pdb.py:82-130 on its hardest fixture: residues are keyed by (chain, number, insertion code);
+    a numbering gap inside a chain is filled with atom-less UNK residues numbered consecutively; residues that share
+    a number and differ by insertion code (antibody CDR numbering) are separate residues and never open a gap."""
+    p = PDB.read_pdb(os.path.join(G, "5cjx_HL.pdb"))
+    unk = [(p.chain_of[k], p.number_of[k]) for k, n in enumerate(p.name_of) if n == "UNK"]
+    assert unk == [("H", 53)] + [("H", n) for n in range(129, 135)]
+    assert p.get_seq_dict()["H"].count("X") == 7 and "X" not in p.get_seq_dict()["L"]
+    assert {c: len(s) for c, s in p.get_seq_dict().items()} == {"H": 234, "L": 214}
+    assert sum(1 for ins in p.insertion_of if ins) == 21
+    # every (chain, number, insertion) key resolves to one residue index and the indices tile [0, n)
+    assert sorted(p.cri2idx.values()) == list(range(p.n_residues))
+    # an insertion-coded run: same number, consecutive indices, all with atoms
+    k = next(i for i, ins in enumerate(p.insertion_of) if ins)
+    assert p.number_of[k] == p.number_of[k - 1] and p.chain_of[k] == p.chain_of[k - 1]
+    xyz, mask = p.get_atom_xyz()
+    assert mask[k].any() and mask[k - 1].any()
+    # the fillers carry their chain's index (so they do not create chain termini) and no coordinates
+    filler = [i for i, n in enumerate(p.name_of) if n == "UNK"]
+    assert all(p.chain_idx[i] == 0 for i in filler) and not mask[filler].any() and torch.isnan(xyz[filler]).all()
+
+
+def test_two_termini_per_structure_like_the_reference_test():
+    """reference tests/test_StructureBatch.py:43-66 (from_pdb single + multiple): two chains per file -> exactly two
+    N-termini and two C-termini per structure, whatever the padding and the UNK fillers.  Terminus masks here come
+    from the CPU oracle on the reader's tensors (the GPU twin is tests/test_gpu_parity.py::test_from_pdb_termini)."""
+    from oracle import protstruc_oracle as O
+    names = ["15c8_HL.pdb", "1ad0_DC.pdb", "5cjx_HL.pdb", "1a3r_HL.pdb", "1a6v_HL.pdb", "1a6v_JN.pdb", "6dc4.pdb"]
+    xyz, mask, chain_idx, chain_ids, seq, residue_idx = read_batch([os.path.join(G, n) for n in names])
+    assert xyz.shape == (7, 448, 15, 3) and all(len(c) == 2 for c in chain_ids)
+    rmask = mask.any(-1)
+    nterm, cterm = O.n_terminal_mask(chain_idx, rmask), O.c_terminal_mask(chain_idx, rmask)
+    assert nterm.dtype == torch.bool and (nterm.sum(1) == 2).all() and (cterm.sum(1) == 2).all()
+    for b, name in enumerate(names):
+        n = PDB.read_pdb(os.path.join(G, name)).n_residues
+        first_of_second_chain = int((chain_idx[b, :n] == 1).nonzero()[0])
+        assert nterm[b].nonzero().flatten().tolist() == [0, first_of_second_chain]
+        assert cterm[b].nonzero().flatten().tolist() == [first_of_second_chain - 1, n - 1]

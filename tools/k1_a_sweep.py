@@ -1,27 +1,48 @@
-"""K1 store rate for atom counts other than 15 (any-A flat kernel; flat=0 selects the element-per-lane kernel).
-Arguments: key=value K1 tuning, e.g. flat=0 or anya_fl_log2=7."""
-import os, sys
+"""K1 store rate for atom counts other than 15, every kernel that can serve the shape timed in ONE process in
+interleaved rounds (never compare across runs / boxes): flat=1 (the default dispatch: fixed-A flat pattern kernel
+for atom14 / atom37, any-A flat kernel otherwise), flat=3 (any-A flat kernel), flat=0 (element-per-lane kernel);
+plus the default dispatch with only the distance plane / only the mask plane.
+Arguments: key=value K1 tuning applied to every run (e.g. flat_cpw=2), `json=path` writes the table."""
+import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
 import torch
 from protstruc_amd import _lib, ops
+out_json = None
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
-    _lib.set_tuning("k1_" + k, int(v))
+    if k == "json": out_json = v
+    else: _lib.set_tuning("k1_" + k, int(v))
 g = torch.Generator().manual_seed(0)
-for A, N in [(15, 256), (14, 256), (4, 512), (5, 512), (8, 256), (3, 512), (1, 1024), (25, 128), (37, 128), (16, 256)]:
+rows = []
+for A, N in [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (5, 512), (8, 256), (16, 256), (25, 128)]:
     B = max(1, int(8e9 / (N * N * A * A * 5)))
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
     d = torch.empty(B, N, N, A, A, device="cuda"); m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-    try:
-        for _ in range(5): ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
-    except Exception as exc:   # e.g. a forced chunk length whose LDS image does not fit
-        print(f"A={A:3d} N={N:5d}: {exc}"); continue
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(10): ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 10
-    print(f"A={A:3d} N={N:5d} B={B:5d}  {ms:8.3f} ms  {B*N*N*A*A*5/ms/1e9:6.2f} TB/s", flush=True)
+    variants = {"default": (1, True, True), "anyA": (3, True, True), "element": (0, True, True),
+                "default_dist_only": (1, True, False), "default_mask_only": (1, False, True)}
+    best = {k: float("inf") for k in variants}
+    for rnd in range(3):
+        for name, (flat, wd, wm) in variants.items():
+            if name == "element" and rnd > 0: continue    # slow; once is enough
+            _lib.set_tuning("k1_flat", flat)
+            run = lambda: ops.pairwise_distance(xyz, mask, out_dist=d if wd else None, out_mask=m if wm else None,
+                                                want_dist=wd, want_mask=wm)
+            for _ in range(2): run()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5): run()
+            e1.record(); torch.cuda.synchronize()
+            best[name] = min(best[name], e0.elapsed_time(e1) / 5)
+    _lib.set_tuning("k1_flat", 1)
+    nbytes = {"default": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1}
+    row = {"A": A, "N": N, "B": B, **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
+                                     for k, v in best.items()}}
+    rows.append(row)
+    print(f"A={A:3d} N={N:4d} B={B:5d} " + "  ".join(f"{k} {v['TBps']:5.2f}" for k, v in row.items() if isinstance(v, dict)),
+          flush=True)
     del xyz, mask, d, m
+if out_json:
+    with open(out_json, "w") as f: json.dump(rows, f, indent=1)

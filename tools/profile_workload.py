@@ -1,0 +1,62 @@
+#!/usr/bin/python3
+"""Workloads for rocprofv3 (run as `rocprofv3 ... -- python3 tools/profile_workload.py <what> [reps]`):
+
+    k3      BASELINE config 3 (B=128, N_res=512): pairwise_dihedrals (2,2) CA,CB|CA,CB and (3,1) N,CA,CB|CB,
+            pairwise_planar_angles (2,1) CA,CB|CB, and the fused inter_residue_geometry
+    k1a     K1 at atom14 (N=256) and atom37 (N=128), ~8 GB of output each: default dispatch (fixed-A flat pattern
+            kernel) and the any-A flat kernel (k1_flat=3)
+    k1      the headline K1 launch (B=64, N=512, A=15)
+Every kernel is launched `reps` times (default 10) after 2 warm-ups, nothing else runs on the GPU."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
+import torch
+
+from protstruc_amd import StructureBatch, _lib, ops
+
+what = sys.argv[1] if len(sys.argv) > 1 else "k3"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+g = torch.Generator().manual_seed(0)
+
+
+def synth(B, N, A=15):
+    xyz = torch.randn(B, N, A, 3, generator=g)
+    mask = torch.rand(B, N, A, generator=g) < 0.9
+    mask[:, :, :3] = True
+    return xyz.cuda(), mask.cuda()
+
+
+def repeat(fn):
+    for _ in range(2 + reps):
+        fn()
+    torch.cuda.synchronize()
+
+
+if what == "k3":
+    xyz, mask = synth(128, 512)
+    sb = StructureBatch.from_xyz(xyz, mask)
+    repeat(lambda: sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]))
+    repeat(lambda: sb.pairwise_dihedrals(["N", "CA", "CB"], ["CB"]))
+    repeat(lambda: sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
+    repeat(lambda: sb.inter_residue_geometry())
+elif what == "k1a":
+    for A, N in ((14, 256), (37, 128)):
+        B = max(1, int(8e9 / (N * N * A * A * 5)))
+        xyz, mask = synth(B, N, A)
+        d = torch.empty(B, N, N, A, A, device="cuda")
+        m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+        for flat in (1, 3):
+            _lib.set_tuning("k1_flat", flat)
+            repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
+        _lib.set_tuning("k1_flat", 1)
+        del xyz, mask, d, m
+elif what == "k1":
+    xyz, mask = synth(64, 512)
+    d = torch.empty(64, 512, 512, 15, 15, device="cuda")
+    m = torch.empty(64, 512, 512, 15, 15, dtype=torch.bool, device="cuda")
+    repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
+else:
+    raise SystemExit(f"unknown workload {what!r}")
+print("done", what, reps)

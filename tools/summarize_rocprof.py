@@ -1,0 +1,69 @@
+#!/usr/bin/python3
+"""Condense rocprofv3 output directories into the small files committed under profiles/.
+
+    python3 tools/summarize_rocprof.py stats <dir> <out.csv>      # *_kernel_stats.csv of a --kernel-trace --stats run
+    python3 tools/summarize_rocprof.py pmc <dir> <out.json> [skip] # *_counter_collection.csv of a --pmc run
+
+`pmc` sums every counter over the dispatches of each kernel (after dropping the first `skip` dispatches of each
+kernel: warm-ups; default 2), and reports per-kernel per-dispatch means.  Counter units are left as rocprofv3 reports
+them (SQ_* cycle counters count quad-cycles summed over all SIMDs / XCDs; see MI355X_MICROARCH.md)."""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits
+
+
+def stats(d, out):
+    rows = []
+    for f in find(d, "kernel_stats.csv"):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    with open(out, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["Name", "Calls", "AverageNs", "MinNs", "MaxNs", "StdDev", "TotalDurationNs", "Percentage"])
+        for r in rows:
+            w.writerow([short(r["Name"]), r["Calls"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
+                        r["TotalDurationNs"], r["Percentage"]])
+
+
+def pmc(d, out, skip=2):
+    per = {}
+    for f in find(d, "counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                k = short(r["Kernel_Name"])
+                e = per.setdefault(k, {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                                       "grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"]), "disp": {}})
+                dd = e["disp"].setdefault(int(r["Dispatch_Id"]), {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+                dd[r["Counter_Name"]] = dd.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    res = {}
+    for k, e in per.items():
+        ids = sorted(e["disp"])[skip:] or sorted(e["disp"])
+        names = sorted({c for i in ids for c in e["disp"][i] if c != "t"})
+        res[k] = {"dispatches_used": len(ids), "vgpr": e["vgpr"], "sgpr": e["sgpr"], "lds_bytes": e["lds"], "grid": e["grid"],
+                  "workgroup": e["wg"], "mean_ns_under_pmc": sum(e["disp"][i]["t"] for i in ids) / len(ids),
+                  "per_dispatch_mean": {c: sum(e["disp"][i].get(c, 0.0) for i in ids) / len(ids) for c in names}}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3])
+    else:
+        pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 2)
