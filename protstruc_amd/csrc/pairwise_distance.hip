@@ -963,6 +963,241 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
     }
 }
 
+// ---- fixed-A flat pattern kernel for SMALL atom counts (A*A <= 128: backbone-only layouts, A = 3, 4, 5, 8) ----
+// Same flat pair axis, same pair-position LDS image, same fixed per-lane slot pattern as k1_pairdist_flatA, but a
+// 4-pair group is only A*A <= 128 float4 slots, so the 256 lanes take G = 256 / (A*A) groups per pass: lane t owns
+// slot t % (A*A) of group t / (A*A) of every pass (A = 4: 16 groups = 64 pairs per pass; A = 5: 10 groups, 250 lanes).
+// Lanes of one pass therefore sit in DIFFERENT groups, possibly in different rows, so the row bookkeeping that is
+// wave-uniform in the large-A kernel is per lane here: each lane walks its own (row, next row boundary), reloads its
+// four row atoms only when its row changes, and takes the element-wise path for a group that straddles a row change
+// or the edge of the active range.  The mask plane is handled the same way (G sixteen-pair groups per pass).
+template <int A>
+struct FlatS {
+    static_assert(A >= 1 && A <= 11, "small fixed-A flat kernel: A*A <= 128");
+    static constexpr int AA = A * A;
+    static constexpr int LPR = A <= 4 ? 4 : (A <= 8 ? 8 : 16);
+    static constexpr int RPP = 256 / LPR;
+    static constexpr int RS = A;                                          // float4 slots per staged residue
+    static constexpr int G = 256 / AA;                                    // groups per pass
+    static constexpr int FL_LOG2 = A <= 5 ? 8 : 7;
+    static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
+    static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
+    static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;
+    static constexpr int NPD = (FLn / 4 + G - 1) / G;                     // distance passes per chunk
+    static constexpr int NPM = (FLn / 16 + G - 1) / G;                    // mask passes per chunk
+    static constexpr int MROWS = 2 + 14 / A;                              // mask rows a 16-byte slot can span
+};
+
+template <int A, bool EXACT, bool HASMASK>
+__global__ __launch_bounds__(256, 4) void k1_pairdist_flatS(const float* __restrict__ xyz,
+                                                           const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                           int B, int N, int out_rows, int out_row_origin,
+                                                           unsigned pbeg, unsigned pend, unsigned n_ranges,
+                                                           unsigned range_stride, unsigned cpr, int cpw,
+                                                           int xcd_remap, double rcpN_d, double rcpR_d) {
+    using G_ = FlatS<A>;
+    constexpr int AA = G_::AA, RSn = G_::RS, FLn = G_::FLn, FRn = G_::FRn, LPR = G_::LPR, RPP = G_::RPP, GP = G_::G;
+    constexpr int NPASS = FLn / RPP, RPASS = FRn / RPP;
+    __shared__ __attribute__((aligned(16))) float4 sxj[FLn * RSn];
+    __shared__ __attribute__((aligned(16))) float4 sxi[FRn * RSn];
+    __shared__ uint32_t smj[FLn], smi[FRn], smr[FLn];
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned n = gridDim.x, x = w & 7u;
+        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
+    }
+    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
+    const int pl = tid / LPR, cl = tid % LPR;
+    constexpr uint32_t abits = (1u << A) - 1u;
+
+    const unsigned n_chunks = n_ranges * cpr;
+    for (int cc = 0; cc < cpw; ++cc) {
+        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
+        if (chunk >= n_chunks) break;  // uniform
+        if (cc) __syncthreads();
+        unsigned rg = 0, k = chunk;
+        if (n_ranges > 1) {
+            rg = chunk / cpr;
+            k = chunk - rg * cpr;
+        }
+        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
+        const unsigned P0 = ((rbeg >> G_::FL_LOG2) + k) << G_::FL_LOG2;
+        if (P0 >= rend) continue;  // uniform
+        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
+        const int hi = rend - P0 < (unsigned)FLn ? (int)(rend - P0) : FLn;
+        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
+        if (R0 * (unsigned long long)N > P0) --R0;
+        else if ((R0 + 1ull) * N <= P0) ++R0;
+        const int j_start = (int)(P0 - R0 * (unsigned)N);
+        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
+        if (b0 * (unsigned long long)out_rows > R0) --b0;
+        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
+        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
+        const int nr = (j_start + FLn - 1) / N + 1;  // rows the chunk touches (<= G_::NR)
+
+        // ---- stage ----
+        float vx[NPASS + RPASS], vy[NPASS + RPASS], vz[NPASS + RPASS];
+        unsigned vm[NPASS + RPASS];
+        bool va[NPASS + RPASS];
+        {
+            unsigned rl = udiv_rcp((unsigned)(j_start + pl), (unsigned)N, rcpN);
+            unsigned j = (unsigned)(j_start + pl) - rl * (unsigned)N;
+            const unsigned db = udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
+            unsigned il = il0 + rl - db * (unsigned)out_rows;
+            unsigned res0 = (b0 + db) * (unsigned)N;
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int p = pass * RPP + pl;
+                va[pass] = (p >= lo) && (p < hi) && (cl < A);
+                const unsigned src = va[pass] ? (res0 + j) * A + cl : 0u;
+                vx[pass] = xyz[src * 3u + 0];
+                vy[pass] = xyz[src * 3u + 1];
+                vz[pass] = xyz[src * 3u + 2];
+                vm[pass] = HASMASK ? (unsigned)amask[src] : 1u;
+                j += RPP;                      // RPP (32 / 64) can exceed N (>= 16): several row changes per pass
+                while (j >= (unsigned)N) {
+                    j -= (unsigned)N;
+                    if (++il == (unsigned)out_rows) {
+                        il = 0;
+                        res0 += (unsigned)N;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int rp = 0; rp < RPASS; ++rp) {
+            const unsigned rr = (unsigned)(rp * RPP + pl);
+            const unsigned ilr = il0 + rr;
+            const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
+            const unsigned bb = b0 + db;
+            const unsigned i = ilr - db * (unsigned)out_rows + (unsigned)out_row_origin;
+            const int L = NPASS + rp;
+            va[L] = ((int)rr < nr) && (bb < (unsigned)B) && (cl < A);
+            const unsigned src = va[L] ? (bb * (unsigned)N + i) * A + cl : 0u;
+            vx[L] = xyz[src * 3u + 0];
+            vy[L] = xyz[src * 3u + 1];
+            vz[L] = xyz[src * 3u + 2];
+            vm[L] = HASMASK ? (unsigned)amask[src] : 1u;
+        }
+        constexpr int FIELDS = 64 / LPR;
+#pragma unroll
+        for (int pass = 0; pass < NPASS + RPASS; ++pass) {
+            const bool is_row = pass >= NPASS;
+            const int p = (is_row ? pass - NPASS : pass) * RPP + pl;
+            if (cl < RSn)
+                (is_row ? sxi : sxj)[p * RSn + cl] =
+                    va[pass] ? make_float4(vx[pass], vy[pass], vz[pass], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned long long bal = __ballot(va[pass] && vm[pass] != 0u);
+            if (cl == 0) (is_row ? smi : smj)[p] = (uint32_t)(bal >> (LPR * (pl % FIELDS))) & abits;
+        }
+        __syncthreads();
+        if (dmask && tid < FLn) {
+            const unsigned rl = udiv_rcp((unsigned)(j_start + tid), (unsigned)N, rcpN);
+            smr[tid] = (tid >= lo && tid < hi) ? smi[rl] : 0u;
+        }
+        __syncthreads();
+        if (tid >= GP * AA) continue;   // idle in the sweeps; rejoins at the next chunk's barrier
+        const int gq = tid / AA;        // this lane's group inside a pass
+        const unsigned sl = (unsigned)(tid - gq * AA);   // its slot inside the group
+
+        if (dist) {
+            unsigned offj[4], ai[4], jo[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const unsigned e = 4u * sl + kk;
+                jo[kk] = e / AA;
+                const unsigned r = e - jo[kk] * AA;
+                ai[kk] = r / A;
+                offj[kk] = ((unsigned)gq * 4u + jo[kk]) * RSn + (r - ai[kk] * A);
+            }
+            int rl = 0, nb = N - j_start, rl_loaded = -1;
+            float4 pi[4];
+#pragma unroll 2
+            for (int pass = 0; pass < G_::NPD; ++pass) {
+                const int g = pass * GP + gq;
+                const int p = 4 * g;
+                if (g >= FLn / 4 || p >= hi) break;   // later passes of this lane lie further on still
+                while (nb <= p) {
+                    ++rl;
+                    nb += N;
+                }
+                float* o = dist + (size_t)P0 * AA + (size_t)g * (4 * AA) + 4u * sl;
+                const float4* x = sxj + pass * (GP * 4 * RSn);
+                if (p >= lo && p + 4 <= min(nb, hi)) {   // the whole group inside one row and inside the active range
+                    if (rl != rl_loaded) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) pi[kk] = sxi[rl * RSn + ai[kk]];
+                        rl_loaded = rl;
+                    }
+                    const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
+                    const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
+                    uint4 v;
+                    v.x = __float_as_uint(dist_pp<EXACT>(pi[0], q0));
+                    v.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
+                    v.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
+                    v.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
+                    store16<false>(o, v);
+                } else if (p + 4 > lo) {   // straddles a row change or an edge of the active range: element-wise
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const int pp = p + (int)jo[kk];
+                        if (pp >= lo && pp < hi) {
+                            const int rk = rl + (pp >= nb ? 1 : 0);  // N >= 16: at most one row change per group
+                            o[kk] = dist_pp<EXACT>(sxi[rk * RSn + ai[kk]], x[offj[kk]]);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (dmask) {
+            constexpr int MR = G_::MROWS;
+            const unsigned e0 = 16u * sl;   // byte inside a 16-pair group
+            const unsigned jo = e0 / AA, r = e0 - jo * AA;
+            const unsigned a = r / A, c = r - a * A;
+            unsigned prow[MR], arow[MR];
+            int sh[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const unsigned am = a + m, dp = am / A;   // a 16-byte slot can reach into the second next pair when A = 3
+                prow[m] = min(jo + dp, 15u);              // rows with sh >= 16 contribute nothing (index clamped)
+                arow[m] = am - dp * A;
+                sh[m] = m * A - (int)c;
+            }
+#pragma unroll 1
+            for (int mp = 0; mp < G_::NPM; ++mp) {
+                const int mg = mp * GP + gq;
+                const int pg = 16 * mg;
+                if (mg >= FLn / 16 || pg >= hi) break;
+                if (pg + 16 <= lo) continue;
+                uint32_t win = 0;
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    if (sh[m] < 16) {
+                        const uint32_t col = smj[pg + prow[m]], row = smr[pg + prow[m]];
+                        const uint32_t bits = ((row >> arow[m]) & 1u) ? col : 0u;
+                        win |= sh[m] <= 0 ? (bits >> (-sh[m])) : (bits << sh[m]);
+                    }
+                }
+                win &= 0xFFFFu;
+                uint8_t* og = dmask + (size_t)P0 * AA + (size_t)mg * (16 * AA) + e0;
+                if (pg >= lo && pg + 16 <= hi) {
+                    store16<false>(og, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
+                                                  spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
+                } else {
+                    for (unsigned t = 0; t < 16u; ++t) {
+                        const int pp = pg + (int)((e0 + t) / AA);
+                        if (pp >= lo && pp < hi) og[t] = (uint8_t)((win >> t) & 1u);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
 // Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
 // fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
@@ -1286,11 +1521,12 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
 #undef PS_K1_FLAT
 }
 
-// Fixed-A flat pattern kernel: instantiated for the atom counts real pipelines use next to 15 (atom14, atom37), for
-// 25 (the atom count of the reference's own from_xyz test, tests/test_StructureBatch.py:11-21) and 16;
+// Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37,
+// the backbone-only layouts 3 (N, CA, C), 4 (+O), 5 (+CB) and 8 -- for 25 (the atom count of the reference's own
+// from_xyz test, tests/test_StructureBatch.py:11-21) and 16;
 // A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
 // kernel (cfg.flat == 4).  Other atom counts take the any-A flat kernel.
-bool flatA_has(int A) { return A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
+bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
 
 bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
     if (g.variant != 0 || g.flat == 0 || g.flat == 3 || !flatA_has(A)) return false;
@@ -1302,12 +1538,24 @@ bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int
     return true;
 }
 
+template <int A> struct FlatOf { typedef FlatA<A> type; };
+template <> struct FlatOf<3> { typedef FlatS<3> type; };
+template <> struct FlatOf<4> { typedef FlatS<4> type; };
+template <> struct FlatOf<5> { typedef FlatS<5> type; };
+template <> struct FlatOf<8> { typedef FlatS<8> type; };
+
+template <int A, bool EX, bool HM>
+auto flat_kernel_of() {
+    if constexpr (A * A <= 128) return &k1_pairdist_flatS<A, EX, HM>;
+    else return &k1_pairdist_flatA<A, EX, HM>;
+}
+
 template <int A>
 int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                  int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
                  unsigned range_stride, hipStream_t s) {
     if (pbeg >= pend || n_ranges == 0) return 0;
-    constexpr int L2 = FlatA<A>::FL_LOG2, FLn = FlatA<A>::FLn;
+    constexpr int L2 = FlatOf<A>::type::FL_LOG2, FLn = FlatOf<A>::type::FLn;
     const unsigned cpr = n_ranges == 1 ? ((pend + (FLn - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
@@ -1316,7 +1564,7 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_FLATA(EX_, HM_)                                                                                     \
-    ps_launch(k1_pairdist_flatA<A, EX_, HM_>, dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N,         \
+    ps_launch(flat_kernel_of<A, EX_, HM_>(), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N,          \
               out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_FLATA(true, true) : PS_K1_FLATA(true, false);
     return amask ? PS_K1_FLATA(false, true) : PS_K1_FLATA(false, false);
@@ -1418,6 +1666,10 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         const unsigned r1 = whole ? (unsigned)((unsigned long long)B * out_rows * N) : r0 + (unsigned)rows * (unsigned)N;
         const unsigned nrg = whole ? 1u : (unsigned)B, stride = whole ? 0u : (unsigned)out_rows * (unsigned)N;
         switch (A) {
+            case 3: return launch_flatA<3>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 4: return launch_flatA<4>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 5: return launch_flatA<5>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 8: return launch_flatA<8>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
             case 14: return launch_flatA<14>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
             case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
             case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);

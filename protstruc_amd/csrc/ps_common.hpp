@@ -157,11 +157,47 @@ __device__ __forceinline__ f3v cross3v(f3v u, f3v v) {
     r.z = u.x * v.y - u.y * v.x;
     return r;
 }
+// atan2_ps on both halves: the polynomial, the squares and the quadrant subtractions as packed mul / fma / add
+// (v_pk_*_f32 issue at the scalar rate, so every packed instruction retires two elements' worth); abs / min / max /
+// rcp / selects have no packed fp32 form and stay per element.  Same operations in the same order per element as
+// atan2_ps, hence the same bits (K3's odd last row and the fused featuriser use the scalar routine).
+__device__ __forceinline__ f32x2 atan2_ps_v(f32x2 y, f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)}, ay = {fabsf(y.x), fabsf(y.y)};
+    const f32x2 mx = {fmaxf(ax.x, ay.x), fmaxf(ax.y, ay.y)}, mn = {fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+    f32x2 a = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    a.x = (mx.x == 0.0f) ? 0.0f : a.x;
+    a.y = (mx.y == 0.0f) ? 0.0f : a.y;
+    a.x = (mn.x == __builtin_huge_valf()) ? 1.0f : a.x;
+    a.y = (mn.y == __builtin_huge_valf()) ? 1.0f : a.y;
+    const f32x2 s = a * a;
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 p = k2(0.0028340641874819994f);
+    p = __builtin_elementwise_fma(p, s, k2(-0.016005029901862144f));
+    p = __builtin_elementwise_fma(p, s, k2(0.042587608098983765f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.07495445758104324f));
+    p = __builtin_elementwise_fma(p, s, k2(0.10636754333972931f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.14202570915222168f));
+    p = __builtin_elementwise_fma(p, s, k2(0.19992484152317047f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.3333306610584259f));
+    p = __builtin_elementwise_fma(p, s, k2(1.0f));
+    f32x2 r = a * p;
+    const f32x2 rq = k2(1.5707963267948966f) - r;
+    r.x = (ay.x > ax.x) ? rq.x : r.x;
+    r.y = (ay.y > ax.y) ? rq.y : r.y;
+    const f32x2 rh = k2(3.141592653589793f) - r;
+    r.x = (__float_as_uint(x.x) >> 31) ? rh.x : r.x;
+    r.y = (__float_as_uint(x.y) >> 31) ? rh.y : r.y;
+    r.x = (x.x != x.x || y.x != y.x) ? __builtin_nanf("") : r.x;
+    r.y = (x.y != x.y || y.y != y.y) ? __builtin_nanf("") : r.y;
+    return f32x2{copysignf(r.x, y.x), copysignf(r.y, y.y)};
+}
+
 __device__ __forceinline__ f32x2 dihedral4v(f3v a, f3v b, f3v c, f3v d) {
     const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2 = sub3v(d, c);
     const f3v n1 = cross3v(b0, b1), n2 = cross3v(b2, b1), m = cross3v(n1, n2);
     const f32x2 x = dot3v(n1, n2), ym = dot3v(m, b1), nn = dot3v(b1, b1);
-    return f32x2{atan2_ps(ym.x * __builtin_amdgcn_rsqf(nn.x), x.x), atan2_ps(ym.y * __builtin_amdgcn_rsqf(nn.y), x.y)};
+    const f32x2 yv = ym * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+    return atan2_ps_v(yv, x);
 }
 
 // sqrt_rn_mk on both halves: v_rsq_f32 and the class test per element, the Newton / residual steps as packed fma

@@ -21,8 +21,8 @@ def test_k1_fast_kernels_differential_fuzz():
     rng = np.random.default_rng(20261004)
     SENT = 4321.0
     try:
-        for trial in range(500):
-            A = int(rng.choice([15, 15, 15, 15, 4, 5, 8, 14, 14, 14, 16, 25, 37, 37, 64]))
+        for trial in range(600):
+            A = int(rng.choice([15, 15, 15, 15, 3, 4, 4, 5, 5, 8, 8, 14, 14, 14, 16, 25, 37, 37, 64, 7]))
             B = int(rng.integers(1, 5))
             nmax = {64: 24, 37: 70, 25: 60}.get(A, 200)
             N = int(rng.integers(16, nmax + 1))

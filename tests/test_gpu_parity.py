@@ -213,9 +213,11 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              # the fixed-A flat pattern kernel (atom14 / atom37, and A = 15 as the template's cross-check): shapes that
              # cross rows inside a 4-pair group, chunks that span several rows and structures, N = 16 (shortest)
              (2, 16, 14), (3, 300, 14), (2, 129, 14), (1, 16, 37), (2, 17, 37), (2, 130, 37), (2, 200, 15), (3, 19, 15),
-             (2, 90, 16), (2, 70, 25), (1, 16, 25)]
+             (2, 90, 16), (2, 70, 25), (1, 16, 25),
+             # small fixed-A kernel (several 4-pair groups per pass, per-lane row bookkeeping): N < pairs per pass
+             (3, 16, 3), (2, 100, 3), (4, 16, 4), (2, 17, 4), (3, 19, 5), (2, 300, 5), (2, 23, 8), (2, 200, 8)]
     try:
-        for (B, N, A), flat in [(c, f) for c in cases for f in ((3, 4) if c[2] in (14, 15, 16, 25, 37) else (3,))]:
+        for (B, N, A), flat in [(c, f) for c in cases for f in ((3, 4) if c[2] in (3, 4, 5, 8, 14, 15, 16, 25, 37) else (3,))]:
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
