@@ -62,8 +62,27 @@ def pmc(d, out, skip=2):
         json.dump(res, fh, indent=1, sort_keys=True)
 
 
+def trace(d, out, kernel_substr, last_k):
+    """Per-dispatch durations of the kernels whose name contains `kernel_substr`, from *_kernel_trace.csv."""
+    rows = []
+    for f in find(d, "kernel_trace.csv"):
+        with open(f) as fh:
+            rows += [r for r in csv.DictReader(fh) if kernel_substr in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
+    tail = ms[-last_k:]
+    res = {"kernel": short(rows[0]["Kernel_Name"]) if rows else None, "dispatches": len(ms),
+           "mean_ms_all_dispatches_incl_autotune_and_warmup": sum(ms) / len(ms) if ms else None,
+           f"mean_ms_last_{last_k}_dispatches_timed_region": sum(tail) / len(tail) if tail else None,
+           "min_ms": min(ms) if ms else None, "max_ms": max(ms) if ms else None}
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]))
     else:
         pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 2)
