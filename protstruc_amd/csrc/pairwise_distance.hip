@@ -979,7 +979,7 @@ struct FlatS {
     static constexpr int RPP = 256 / LPR;
     static constexpr int RS = A;                                          // float4 slots per staged residue
     static constexpr int G = 256 / AA;                                    // groups per pass
-    static constexpr int FL_LOG2 = A <= 5 ? 8 : 7;
+    static constexpr int FL_LOG2 = A <= 5 ? 8 : 7;   // A = 5 with 128-pair chunks: 3.19 instead of 3.86 TB/s (profiles/r02_k1_a_sweep_*)
     static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
     static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
     static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;

@@ -255,7 +255,9 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
         args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
         _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A)
         cfg = _lib.k1_config(xyz.device)   # this device's settings, snapshotted for this launch
-        rc = _lib.load().ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfg), _stream(xyz))
+        rc = 0
+        if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfg), _stream(xyz))
     _lib.check(rc, "ps_pairwise_distance_cfg_f32")
     return dist, dmask
 
@@ -277,9 +279,11 @@ def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask:
         dmask = torch.empty(B, N, 3, dtype=torch.bool, device=dev) if want_mask else None
         nterm = torch.empty(B, N, dtype=torch.bool, device=dev) if want_nterm else None
         cterm = torch.empty(B, N, dtype=torch.bool, device=dev) if want_cterm else None
-        rc = _lib.load().ps_backbone_dihedrals_f32(
-            _ptr(xyz), _ptr(chain), _ptr(rmask), _ptr(dih), _ptr(dmask), _ptr(nterm), _ptr(cterm), B, N, A,
-            _stream(xyz))
+        rc = 0
+        if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_backbone_dihedrals_f32(
+                _ptr(xyz), _ptr(chain), _ptr(rmask), _ptr(dih), _ptr(dmask), _ptr(nterm), _ptr(cterm), B, N, A,
+                _stream(xyz))
     _lib.check(rc, "ps_backbone_dihedrals_f32")
     return dih, dmask, nterm, cterm
 
@@ -308,9 +312,11 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
             out = torch.empty(B, out_rows, N, dtype=torch.float32, device=xyz.device)
         else:
             _check_out(out, (B, out_rows, N), "out", xyz.device)
-        rc = _lib.load().ps_pairwise_angles_f32(
-            _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
-            _stream(xyz))
+        rc = 0
+        if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_pairwise_angles_f32(
+                _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
+                _stream(xyz))
     _lib.check(rc, "ps_pairwise_angles_f32")
     return out
 
@@ -328,8 +334,10 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
     with torch.cuda.device(dev):
         f = torch.empty(6, B, N, N, dtype=torch.float32, device=dev)
         k = torch.empty(3, B, N, N, dtype=torch.bool, device=dev)
-        rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[_ptr(f[i]) for i in range(6)],
-                                                       *[_ptr(k[i]) for i in range(3)], B, N, A, _stream(xyz))
+        rc = 0
+        if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[_ptr(f[i]) for i in range(6)],
+                                                           *[_ptr(k[i]) for i in range(3)], B, N, A, _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
     out = {name: f[i] for i, name in enumerate(fkeys)}
     out.update({name: k[i] for i, name in enumerate(mkeys)})
@@ -348,8 +356,10 @@ def pointwise(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, d: O
     dev = flat[0].device
     with torch.cuda.device(dev):
         out = torch.empty((n, 9) if mode == 2 else (n,), dtype=torch.float32, device=dev)
-        rc = _lib.load().ps_pointwise_f32(mode, _ptr(flat[0]), _ptr(flat[1]), _ptr(flat[2]),
-                                          _ptr(flat[3]) if mode == 1 else None, _ptr(out), n, _stream(flat[0]))
+        rc = 0
+        if not (n == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_pointwise_f32(mode, _ptr(flat[0]), _ptr(flat[1]), _ptr(flat[2]),
+                                              _ptr(flat[3]) if mode == 1 else None, _ptr(out), n, _stream(flat[0]))
     _lib.check(rc, "ps_pointwise_f32")
     return out.reshape(*shape, 3, 3) if mode == 2 else out.reshape(shape)
 
@@ -363,8 +373,10 @@ def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, wan
     with torch.cuda.device(dev):
         rot = torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None
         trans = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_trans else None
-        rc = _lib.load().ps_frames_f32(_ptr(xyz), _ptr(rot), _ptr(trans), B, N, A, int(a1), int(a2), int(a3),
-                                       int(t_atom), _stream(xyz))
+        rc = 0
+        if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_frames_f32(_ptr(xyz), _ptr(rot), _ptr(trans), B, N, A, int(a1), int(a2), int(a3),
+                                           int(t_atom), _stream(xyz))
     _lib.check(rc, "ps_frames_f32")
     return rot, trans
 
@@ -390,7 +402,9 @@ def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Te
     _check_rng_state(rng_state, xyz.device)
     _same_device(xyz, beta=beta, noise=noise)
     with torch.cuda.device(xyz.device):
-        rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
     _lib.check(rc, "ps_diffuse_f32")
     return xyz
 
@@ -423,8 +437,10 @@ def diffuse_frames_(xyz: torch.Tensor, beta: torch.Tensor, a1: int, a2: int, a3:
     with torch.cuda.device(dev):
         rot = out_rot if out_rot is not None else torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev)
         trans = out_trans if out_trans is not None else torch.empty(B, N, 3, dtype=torch.float32, device=dev)
-        rc = _lib.load().ps_diffuse_frames_f32(_ptr(xyz), _ptr(beta), B, N, A, _ptr(rng_state), _ptr(noise), _ptr(rot),
-                                               _ptr(trans), int(a1), int(a2), int(a3), int(t_atom), _stream(xyz))
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_diffuse_frames_f32(_ptr(xyz), _ptr(beta), B, N, A, _ptr(rng_state), _ptr(noise), _ptr(rot),
+                                                   _ptr(trans), int(a1), int(a2), int(a3), int(t_atom), _stream(xyz))
     _lib.check(rc, "ps_diffuse_frames_f32")
     return rot, trans
 
@@ -462,9 +478,11 @@ def diffusion_trajectory_(xyz: torch.Tensor, betas: torch.Tensor, a1: int, a2: i
             torch.empty(T, B, N, 3, dtype=torch.float32, device=dev) if want_trans else None)
         traj = out_xyz if out_xyz is not None else (
             torch.empty(T, B, N, A, 3, dtype=torch.float32, device=dev) if want_xyz else None)
-        rc = _lib.load().ps_diffusion_trajectory_f32(_ptr(xyz), _ptr(betas), T, B, N, A, _ptr(rng_state), _ptr(rot),
-                                                     _ptr(trans), _ptr(traj), int(a1), int(a2), int(a3), int(t_atom),
-                                                     _stream(xyz))
+        rc = 0
+        if not (xyz.numel() == 0 or T == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_diffusion_trajectory_f32(_ptr(xyz), _ptr(betas), T, B, N, A, _ptr(rng_state), _ptr(rot),
+                                                         _ptr(trans), _ptr(traj), int(a1), int(a2), int(a3), int(t_atom),
+                                                         _stream(xyz))
     _lib.check(rc, "ps_diffusion_trajectory_f32")
     return rot, trans, traj
 
@@ -478,9 +496,13 @@ def standardize_(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor]):
     m = _u8c(atom_mask, "atom_mask")
     dev = xyz.device
     with torch.cuda.device(dev):
-        mu = torch.empty(B, 3, dtype=torch.float32, device=dev)
-        std = torch.empty(B, 3, dtype=torch.float32, device=dev)
-        rc = _lib.load().ps_standardize_f32(_ptr(xyz), _ptr(m), _ptr(mu), _ptr(std), B, N, A, _stream(xyz))
+        # a structure without atoms has 0 / 0 statistics in the reference: NaN, not uninitialised memory
+        alloc = torch.empty if N * A > 0 else (lambda *a, **k: torch.full(a, float("nan"), **k))
+        mu = alloc(B, 3, dtype=torch.float32, device=dev)
+        std = alloc(B, 3, dtype=torch.float32, device=dev)
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_standardize_f32(_ptr(xyz), _ptr(m), _ptr(mu), _ptr(std), B, N, A, _stream(xyz))
     _lib.check(rc, "ps_standardize_f32")
     return mu, std
 
@@ -495,7 +517,9 @@ def affine_(xyz: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torc
     scale = _f32c(scale, "scale")
     shift = _f32c(shift, "shift")
     with torch.cuda.device(xyz.device):
-        rc = _lib.load().ps_affine_f32(_ptr(xyz), _ptr(scale), _ptr(shift), B, n_atoms, _stream(xyz))
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_affine_f32(_ptr(xyz), _ptr(scale), _ptr(shift), B, n_atoms, _stream(xyz))
     _lib.check(rc, "ps_affine_f32")
     return xyz
 
@@ -531,8 +555,10 @@ def rigid(xyz: torch.Tensor, R: Optional[torch.Tensor] = None, t: Optional[torch
         t = t.contiguous()
     with torch.cuda.device(xyz.device):
         out = xyz if inplace else torch.empty_like(xyz)
-        rc = _lib.load().ps_rigid_f32(_ptr(xyz), _ptr(out), _ptr(R), r_mode, int(transpose), _ptr(t), t_mode, B, N, A,
-                                      _stream(xyz))
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_rigid_f32(_ptr(xyz), _ptr(out), _ptr(R), r_mode, int(transpose), _ptr(t), t_mode, B, N, A,
+                                          _stream(xyz))
     _lib.check(rc, "ps_rigid_f32")
     return out
 
@@ -542,8 +568,12 @@ def center_of_mass(xyz: torch.Tensor, atom: int = 1) -> torch.Tensor:
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     with torch.cuda.device(xyz.device):
-        com = torch.empty(B, 3, dtype=torch.float32, device=xyz.device)
-        rc = _lib.load().ps_center_of_mass_f32(_ptr(xyz), _ptr(com), B, N, A, int(atom), _stream(xyz))
+        # no residues: the reference's nanmean over nothing is NaN
+        com = (torch.empty if xyz.numel() else (lambda *a, **k: torch.full(a, float("nan"), **k)))(
+            B, 3, dtype=torch.float32, device=xyz.device)
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_center_of_mass_f32(_ptr(xyz), _ptr(com), B, N, A, int(atom), _stream(xyz))
     _lib.check(rc, "ps_center_of_mass_f32")
     return com
 
@@ -558,8 +588,10 @@ def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, ideal: torch.Tens
     ideal = _f32c(ideal.to(rot.device), "ideal")
     with torch.cuda.device(rot.device):
         xyz = torch.empty(B, N, n_slots, 3, dtype=torch.float32, device=rot.device)
-        rc = _lib.load().ps_frames_to_backbone_f32(_ptr(rot), _ptr(trans), _ptr(ideal), ideal.shape[0], _ptr(xyz), B, N,
-                                                   n_slots, _stream(rot))
+        rc = 0
+        if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
+            rc = _lib.load().ps_frames_to_backbone_f32(_ptr(rot), _ptr(trans), _ptr(ideal), ideal.shape[0], _ptr(xyz), B, N,
+                                                       n_slots, _stream(rot))
     _lib.check(rc, "ps_frames_to_backbone_f32")
     return xyz
 

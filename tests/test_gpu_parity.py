@@ -1428,6 +1428,37 @@ def test_input_flavours(SB):
     assert_close(t, g["kabsch_t"], tol=5e-5)
 
 
+@pytest.mark.parametrize("B,N", [(0, 8), (2, 0), (0, 0)])
+def test_empty_batches(SB, B, N):
+    """Empty inputs (no structures, or structures without residues) go through every featuriser: empty outputs of
+    the reference's shapes and dtypes, nothing launched, nothing raised."""
+    A = 15
+    xyz = torch.zeros(B, N, A, 3)
+    mask = torch.zeros(B, N, A, dtype=torch.bool)
+    sb = SB.from_xyz(xyz, mask)
+    d, m = sb.pairwise_distance_matrix()
+    assert d.shape == (B, N, N, A, A) and d.dtype == torch.float32 and m.shape == d.shape and m.dtype == torch.bool
+    dih, dm = sb.backbone_dihedrals()
+    assert dih.shape == (B, N, 3) and dm.shape == (B, N, 3) and dm.dtype == torch.bool
+    assert sb.get_n_terminal_mask().shape == (B, N) and sb.get_c_terminal_mask().shape == (B, N)
+    assert sb.backbone_orientations().shape == (B, N, 3, 3) and sb.backbone_translations().shape == (B, N, 3)
+    assert sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]).shape == (B, N, N)
+    assert sb.pairwise_planar_angles(["CA", "CB"], ["CB"]).shape == (B, N, N)
+    geo = sb.inter_residue_geometry()
+    assert all(v.shape == (B, N, N) for v in geo.values()) and len(geo) == 9
+    sb.manual_seed(3).diffuse_xyz(torch.full((B,), 0.1))
+    rot, tr = sb.diffuse_xyz_and_frames(torch.full((B,), 0.1))
+    assert rot.shape == (B, N, 3, 3) and tr.shape == (B, N, 3)
+    r3, t3, x3 = sb.diffuse_trajectory(torch.full((4, B), 0.1), want_xyz=True)
+    assert r3.shape == (4, B, N, 3, 3) and t3.shape == (4, B, N, 3) and x3.shape == (4, B, N, A, 3)
+    sb.standardize()
+    assert sb.mu.shape == (B, 3) and sb.std.shape == (B, 3) and sb.mu.isnan().all()
+    sb.unstandardize()
+    assert sb.center_of_mass().shape == (B, 3)
+    torch.cuda.synchronize()
+    assert sb.get_xyz().shape == (B, N, A, 3)
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")
