@@ -138,6 +138,9 @@ _k1_table = {}   # device index -> {field: value}
 
 
 def _device_index(device=None):
+    idx = getattr(device, "index", None)     # torch.device with an explicit index: the hot path
+    if idx is not None:
+        return idx
     if device is None:
         import torch
         return torch.cuda.current_device() if torch.cuda.is_available() else 0
@@ -166,10 +169,24 @@ def _k1_entry(device):
         return _k1_table[idx]
 
 
+_k1_structs = {}   # device index -> ps_k1_config built from the table entry; REPLACED (never mutated) by set_tuning
+
+
 def k1_config(device=None, **overrides):
-    """Snapshot of ``device``'s K1 configuration as a ``ps_k1_config`` struct (fields overridden by keyword)."""
+    """Snapshot of ``device``'s K1 configuration as a ``ps_k1_config`` struct (fields overridden by keyword).
+    Without overrides the struct is the cached one of the device's current settings: it is never modified in place
+    (a change of settings installs a new struct), and the library copies it by value before launching, so sharing
+    it between launches and threads keeps the snapshot semantics."""
+    idx = _device_index(device)
+    if not overrides:
+        cfg = _k1_structs.get(idx)
+        if cfg is not None:
+            return cfg
     with _k1_lock:
-        d = dict(_k1_entry(device))
+        d = dict(_k1_entry(idx))
+        if not overrides:
+            cfg = _k1_structs[idx] = K1Config(**d)
+            return cfg
     d.update(overrides)
     return K1Config(**d)
 
@@ -187,7 +204,9 @@ def set_tuning(key, value, device=None):
         raise HipLibraryError("timing experiments are not compiled into the product library "
                               "(build with `python -m protstruc_amd.build --experiments` and set PROTSTRUC_AMD_LIB)")
     with _k1_lock:
-        _k1_entry(device)[field] = value
+        idx = _device_index(device)
+        _k1_entry(idx)[field] = value
+        _k1_structs.pop(idx, None)     # the next launch builds a fresh struct; structs in flight stay as they were
 
 
 def get_tuning(key, device=None):

@@ -75,11 +75,31 @@ def _check_out(t: Optional[torch.Tensor], shape, name: str, device: torch.device
 
 
 def _ptr(t: Optional[torch.Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    # a plain int is what ctypes wants for a c_void_p argument (None = NULL); no wrapper object per pointer
+    return None if t is None else t.data_ptr()
 
 
 def _stream(t: torch.Tensor):
-    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NoSwitch:
+    """`with` target used when the tensor's device is already the current one (the common case): entering
+    torch.cuda.device() costs two device switches, about a quarter of a small call's host time."""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device: torch.device):
+    """Context that makes ``device`` current for allocations and launches."""
+    return _NO_SWITCH if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
 # ---- one-time, per-device choice of K1's output granule per workgroup ----------------------------------------
@@ -190,7 +210,7 @@ def allocate_fast_outputs(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] =
     B, N, A = xyz.shape[:3]
     shape = (B, N, N, A, A)
     pairs = []
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         for _ in range(max(1, int(candidates))):
             pairs.append((torch.empty(shape, dtype=torch.float32, device=xyz.device),
                           torch.empty(shape, dtype=torch.bool, device=xyz.device)))
@@ -242,7 +262,7 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
     out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
     shape = (B, out_rows, N, A, A)
     mask_u8 = _u8c(atom_mask, "atom_mask")
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         dist = dmask = None
         if want_dist:
             dist = out_dist if out_dist is not None else torch.empty(shape, dtype=torch.float32, device=xyz.device)
@@ -274,7 +294,7 @@ def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask:
     dev = xyz.device
     if not (want_dihedrals or want_mask or want_nterm or want_cterm):
         raise ValueError("at least one output must be requested")
-    with torch.cuda.device(dev):
+    with _on(dev):
         dih = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_dihedrals else None
         dmask = torch.empty(B, N, 3, dtype=torch.bool, device=dev) if want_mask else None
         nterm = torch.empty(B, N, dtype=torch.bool, device=dev) if want_nterm else None
@@ -307,7 +327,7 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
         raise ValueError(f"row range [{row_begin},{row_end}) outside [0,{N})")
     out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
     arr = ctypes.c_int * n_points
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         if out is None:
             out = torch.empty(B, out_rows, N, dtype=torch.float32, device=xyz.device)
         else:
@@ -331,16 +351,17 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
     dev = xyz.device
     fkeys = ["d_ca", "d_cb", "d_no", "omega", "theta", "phi"]
     mkeys = ["d_ca_mask", "d_cb_mask", "d_no_mask"]
-    with torch.cuda.device(dev):
+    with _on(dev):
         f = torch.empty(6, B, N, N, dtype=torch.float32, device=dev)
         k = torch.empty(3, B, N, N, dtype=torch.bool, device=dev)
         rc = 0
         if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
-            rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[_ptr(f[i]) for i in range(6)],
-                                                           *[_ptr(k[i]) for i in range(3)], B, N, A, _stream(xyz))
+            fp, kp, plane = f.data_ptr(), k.data_ptr(), B * N * N     # plane addresses by arithmetic, not by 9 views
+            rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * plane * i for i in range(6)],
+                                                           *[kp + plane * i for i in range(3)], B, N, A, _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
-    out = {name: f[i] for i, name in enumerate(fkeys)}
-    out.update({name: k[i] for i, name in enumerate(mkeys)})
+    out = dict(zip(fkeys, f.unbind(0)))
+    out.update(zip(mkeys, k.unbind(0)))
     return out
 
 
@@ -354,7 +375,7 @@ def pointwise(mode: int, a: torch.Tensor, b: torch.Tensor, c: torch.Tensor, d: O
     flat = [p.reshape(-1, 3).contiguous() for p in pts]
     n = flat[0].shape[0]
     dev = flat[0].device
-    with torch.cuda.device(dev):
+    with _on(dev):
         out = torch.empty((n, 9) if mode == 2 else (n,), dtype=torch.float32, device=dev)
         rc = 0
         if not (n == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
@@ -370,7 +391,7 @@ def frames(xyz: torch.Tensor, a1: int, a2: int, a3: int, t_atom: int = 1, *, wan
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     dev = xyz.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         rot = torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None
         trans = torch.empty(B, N, 3, dtype=torch.float32, device=dev) if want_trans else None
         rc = 0
@@ -401,7 +422,7 @@ def diffuse_(xyz: torch.Tensor, beta: torch.Tensor, rng_state: Optional[torch.Te
         raise ValueError("either rng_state or noise is required")
     _check_rng_state(rng_state, xyz.device)
     _same_device(xyz, beta=beta, noise=noise)
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         rc = 0
         if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
             rc = _lib.load().ps_diffuse_f32(_ptr(xyz), _ptr(beta), B, nps, _ptr(rng_state), _ptr(noise), _stream(xyz))
@@ -434,7 +455,7 @@ def diffuse_frames_(xyz: torch.Tensor, beta: torch.Tensor, a1: int, a2: int, a3:
     dev = xyz.device
     _check_out(out_rot, (B, N, 3, 3), "out_rot", dev)
     _check_out(out_trans, (B, N, 3), "out_trans", dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rot = out_rot if out_rot is not None else torch.empty(B, N, 3, 3, dtype=torch.float32, device=dev)
         trans = out_trans if out_trans is not None else torch.empty(B, N, 3, dtype=torch.float32, device=dev)
         rc = 0
@@ -471,7 +492,7 @@ def diffusion_trajectory_(xyz: torch.Tensor, betas: torch.Tensor, a1: int, a2: i
     _check_out(out_rot, (T, B, N, 3, 3), "out_rot", dev)
     _check_out(out_trans, (T, B, N, 3), "out_trans", dev)
     _check_out(out_xyz, (T, B, N, A, 3), "out_xyz", dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         rot = out_rot if out_rot is not None else (
             torch.empty(T, B, N, 3, 3, dtype=torch.float32, device=dev) if want_rot else None)
         trans = out_trans if out_trans is not None else (
@@ -495,7 +516,7 @@ def standardize_(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor]):
     B, N, A = xyz.shape[:3]
     m = _u8c(atom_mask, "atom_mask")
     dev = xyz.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         # a structure without atoms has 0 / 0 statistics in the reference: NaN, not uninitialised memory
         alloc = torch.empty if N * A > 0 else (lambda *a, **k: torch.full(a, float("nan"), **k))
         mu = alloc(B, 3, dtype=torch.float32, device=dev)
@@ -516,7 +537,7 @@ def affine_(xyz: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor) -> torc
     n_atoms = xyz[0].numel() // 3 if B else 0
     scale = _f32c(scale, "scale")
     shift = _f32c(shift, "shift")
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         rc = 0
         if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
             rc = _lib.load().ps_affine_f32(_ptr(xyz), _ptr(scale), _ptr(shift), B, n_atoms, _stream(xyz))
@@ -553,7 +574,7 @@ def rigid(xyz: torch.Tensor, R: Optional[torch.Tensor] = None, t: Optional[torch
         else:
             raise ValueError(f"translation shape {tuple(t.shape)} does not broadcast against xyz {tuple(xyz.shape)}")
         t = t.contiguous()
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         out = xyz if inplace else torch.empty_like(xyz)
         rc = 0
         if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
@@ -567,7 +588,7 @@ def center_of_mass(xyz: torch.Tensor, atom: int = 1) -> torch.Tensor:
     """(B,3) nanmean over residues of one atom slot."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
-    with torch.cuda.device(xyz.device):
+    with _on(xyz.device):
         # no residues: the reference's nanmean over nothing is NaN
         com = (torch.empty if xyz.numel() else (lambda *a, **k: torch.full(a, float("nan"), **k)))(
             B, 3, dtype=torch.float32, device=xyz.device)
@@ -586,7 +607,7 @@ def frames_to_backbone(rot: torch.Tensor, trans: torch.Tensor, ideal: torch.Tens
     if rot.shape != (B, N, 3, 3) or trans.shape != (B, N, 3):
         raise ValueError("orientations must be (B,N,3,3) and translations (B,N,3)")
     ideal = _f32c(ideal.to(rot.device), "ideal")
-    with torch.cuda.device(rot.device):
+    with _on(rot.device):
         xyz = torch.empty(B, N, n_slots, 3, dtype=torch.float32, device=rot.device)
         rc = 0
         if not (xyz.numel() == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
@@ -608,7 +629,7 @@ def kabsch(src: torch.Tensor, dst: torch.Tensor, atom_mask: torch.Tensor):
     if m.shape[0] not in (1, B):
         raise ValueError("atom_mask must have the batch size of the source (or 1)")
     dev = src.device
-    with torch.cuda.device(dev):
+    with _on(dev):
         R = torch.empty(B, 3, 3, dtype=torch.float32, device=dev)
         t = torch.empty(B, 3, dtype=torch.float32, device=dev)
         rc = _lib.load().ps_kabsch_f32(_ptr(src), _ptr(dst), _ptr(m), _ptr(R), _ptr(t), B, n_atoms,
@@ -622,7 +643,7 @@ def min_dist_to_points(xyz_one: torch.Tensor, query: torch.Tensor, atom: int = 1
     xyz_one = _f32c(xyz_one, "xyz")
     query = _f32c(query.to(xyz_one.device), "query_xyz").reshape(-1, 3)
     N, A = xyz_one.shape[:2]
-    with torch.cuda.device(xyz_one.device):
+    with _on(xyz_one.device):
         out = torch.empty(N, dtype=torch.float32, device=xyz_one.device)
         rc = _lib.load().ps_min_dist_to_points_f32(_ptr(xyz_one), _ptr(query), _ptr(out), N, A, int(atom),
                                                    query.shape[0], _stream(xyz_one))

@@ -59,6 +59,24 @@ def test_k1_golden(SB, name):
     assert torch.equal(m.cpu(), g["dist_mask"])
 
 
+@pytest.mark.parametrize("A", [14, 37, 25, 3, 4, 5, 8, 16])
+def test_k1_golden_other_atom_counts(SB, A):
+    """G13: the reference itself at the atom counts that take the fixed-A flat pattern kernels (N >= 16): sampled whole
+    (b,i,j) blocks within 1e-5 with NaN positions exact, mask blocks and every pair's mask count exact, per-pair
+    distance sums.  (`from_xyz` accepts any atom count: reference protstruc.py:94-128, tests/test_StructureBatch.py:11-21.)"""
+    g = load_golden("g13_dist_atom_counts")
+    t = f"a{A}"
+    sb = SB.from_xyz(g[f"{t}_xyz"], g[f"{t}_atom_mask"])
+    d, m = sb.pairwise_distance_matrix()
+    assert m.dtype == torch.bool and d.shape[-1] == A
+    b, i, j = g[f"{t}_b"].long().cuda(), g[f"{t}_i"].long().cuda(), g[f"{t}_j"].long().cuda()
+    assert_close(d[b, i, j], g[f"{t}_dist_blocks"])
+    assert torch.equal(m[b, i, j].cpu(), g[f"{t}_mask_blocks"])
+    assert torch.equal(m.sum((3, 4)).to(torch.int32).cpu(), g[f"{t}_mask_row_sums"])
+    sums = torch.nan_to_num(d, nan=0.0).double().sum((3, 4)).float().cpu()
+    assert torch.allclose(sums, g[f"{t}_dist_row_nansum"], rtol=2e-6, atol=1e-4)
+
+
 def test_k1_golden_protein_scale(SB):
     g = load_golden("g1_dist_b1_n12_protein_scale")
     d, m = SB.from_xyz(g["xyz"], g["atom_mask"]).pairwise_distance_matrix()

@@ -202,3 +202,24 @@ def test_align_topk_select():
     assert torch.equal(O.topk_nearest_residue_mask(xyz[0], rmask, g["query"], 8, g["topk_user_mask"]), g["topk_masked"])
     assert torch.equal(O.topk_nearest_residue_mask(xyz[0], rmask, g["query"]), g["topk_all"])
     assert torch.equal(xyz[:1][g["pick"]].unsqueeze(0), g["picked_xyz"])
+
+
+ATOM_COUNTS = (14, 37, 25, 3, 4, 5, 8, 16)
+
+
+@pytest.mark.parametrize("A", ATOM_COUNTS)
+def test_oracle_matches_reference_at_other_atom_counts(A):
+    """G13 (tools/make_golden_atom_counts.py): the reference's pairwise_distance_matrix at atom14 / atom37 / 25 and
+    the backbone-only layouts, N >= 16 -- sampled whole blocks, exact per-pair mask counts, per-pair distance sums."""
+    g = load_golden("g13_dist_atom_counts")
+    t = f"a{A}"
+    xyz, mask = g[f"{t}_xyz"], g[f"{t}_atom_mask"]
+    d, m = O.pairwise_distance_matrix(xyz, mask)
+    b, i, j = g[f"{t}_b"].long(), g[f"{t}_i"].long(), g[f"{t}_j"].long()
+    got, want = d[b, i, j], g[f"{t}_dist_blocks"]
+    assert torch.equal(torch.isnan(got), torch.isnan(want))
+    assert (got - want).abs().nan_to_num(0).max() <= 1e-6
+    assert torch.equal(m[b, i, j], g[f"{t}_mask_blocks"])
+    assert torch.equal(m.sum((3, 4)).to(torch.int32), g[f"{t}_mask_row_sums"])
+    sums = torch.nan_to_num(d, nan=0.0).double().sum((3, 4)).float()
+    assert torch.allclose(sums, g[f"{t}_dist_row_nansum"], rtol=1e-6, atol=1e-5)
