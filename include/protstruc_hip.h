@@ -194,6 +194,13 @@ int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_struct,
 int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std,
                        int B, int N, int A, void* stream);
 
+/* The same with the kernel chosen explicitly: variant 0 = what ps_standardize_f32 does (the LDS-resident kernel --
+ * one read and one write of the coordinates -- when a structure fits in 150 KB of LDS, i.e. N*A <= 12800 atoms);
+ * variant 1 = always the three-sweep streaming kernel.  Both produce the same bits; this entry point exists for
+ * that cross-check and for timing. */
+int ps_standardize_variant_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std,
+                               int B, int N, int A, int variant, void* stream);
+
 /*
  * Replaces StructureBatch.unstandardize (protstruc.py:736-744), in place:
  *   xyz[b] <- xyz[b] * scale[b] + shift[b]   per coordinate axis; scale, shift are (B,3).

@@ -55,6 +55,7 @@ SIGNATURES = {
     "ps_kabsch_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_min_dist_to_points_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_standardize_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_standardize_variant_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_affine_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_stream]),
 }
 

@@ -418,6 +418,68 @@ __global__ __launch_bounds__(1024) void k6_standardize(float* __restrict__ xyz, 
     }
 }
 
+// K6, LDS-resident form: the structure (n_atoms * 3 floats; 69 KB at the config-5 shape) is read from HBM ONCE into
+// LDS, both statistics sweeps and the normalisation run on the LDS copy, and the result is written once -- 1 read +
+// 1 write of the coordinates instead of 3 + 1.  Per thread the accumulation visits the same atoms in the same order
+// as k6_standardize and the block reductions are the same, so mu, std and the output are bit-identical to it
+// (tests/test_gpu_parity.py::test_k6_lds_resident_equals_streaming).  Used when the structure fits (<= 150 KB).
+__global__ __launch_bounds__(1024) void k6_standardize_lds(float* __restrict__ xyz, const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ mu_out, float* __restrict__ std_out,
+                                                           int n_atoms) {
+    extern __shared__ __attribute__((aligned(16))) float sx[];   // n_atoms * 3 coordinates
+    __shared__ double red[68];
+    const int b = blockIdx.x;
+    const int nf = n_atoms * 3;
+    float* x = xyz + (size_t)b * nf;
+    const uint8_t* m = amask ? amask + (size_t)b * n_atoms : nullptr;
+
+    // coalesced copy in: float4 where the structure starts 16-byte aligned, dwords otherwise / for the tail
+    const bool v4 = ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int n4 = v4 ? nf >> 2 : 0;
+    for (int q = threadIdx.x; q < n4; q += blockDim.x)
+        reinterpret_cast<float4*>(sx)[q] = reinterpret_cast<const float4*>(x)[q];
+    for (int f = 4 * n4 + threadIdx.x; f < nf; f += blockDim.x) sx[f] = x[f];
+    __syncthreads();
+
+    double acc[4] = {0, 0, 0, 0};  // sum x, sum y, sum z, count
+    for (int a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+        const float w = m ? (m[a] ? 1.f : 0.f) : 1.f;
+        acc[0] += (double)nan_to_num0(sx[a * 3 + 0] * w);
+        acc[1] += (double)nan_to_num0(sx[a * 3 + 1] * w);
+        acc[2] += (double)nan_to_num0(sx[a * 3 + 2] * w);
+        acc[3] += (double)w;
+    }
+    block_sum4(acc, red);
+    const float cnt = (float)acc[3];
+    const float mu[3] = {(float)acc[0] / cnt, (float)acc[1] / cnt, (float)acc[2] / cnt};
+
+    double sq[4] = {0, 0, 0, 0};
+    for (int a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+        const float w = m ? (m[a] ? 1.f : 0.f) : 1.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float d = nan_to_num0(sx[a * 3 + k]) - mu[k];
+            sq[k] += (double)((d * d) * w);
+        }
+    }
+    block_sum4(sq, red);
+    const float sd[3] = {sqrtf((float)sq[0] / cnt), sqrtf((float)sq[1] / cnt), sqrtf((float)sq[2] / cnt)};
+
+    // normalise in LDS (atom-major, so every thread knows its axis without a division), then stream out coalesced
+    for (int a = threadIdx.x; a < n_atoms; a += blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sx[a * 3 + k] = (sx[a * 3 + k] - mu[k]) / sd[k];
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < n4; q += blockDim.x)
+        reinterpret_cast<float4*>(x)[q] = reinterpret_cast<const float4*>(sx)[q];
+    for (int f = 4 * n4 + threadIdx.x; f < nf; f += blockDim.x) x[f] = sx[f];
+    if (threadIdx.x < 3) {
+        mu_out[b * 3 + threadIdx.x] = mu[threadIdx.x];
+        std_out[b * 3 + threadIdx.x] = sd[threadIdx.x];
+    }
+}
+
 __global__ __launch_bounds__(256) void k6_affine(float* __restrict__ xyz, const float* __restrict__ scale,
                                                  const float* __restrict__ shift, unsigned n_atoms, size_t total_atoms) {
     const size_t a = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -444,12 +506,28 @@ extern "C" int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_st
                        (unsigned)n_total, (unsigned)n_per_struct, (unsigned)B, rng_state, noise);
 }
 
-extern "C" int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std, int B, int N, int A,
-                                  void* stream) {
+// Dispatch: LDS-resident kernel when one structure fits in 150 KB of LDS, the three-sweep kernel otherwise.
+// `force_streaming` (ps_standardize_variant_f32 only) exists so that the two can be compared bit for bit.
+static int standardize_dispatch(float* xyz, const uint8_t* atom_mask, float* mu, float* std, int B, int N, int A,
+                                bool force_streaming, void* stream) {
     if (!xyz || !mu || !std || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    return ps_launch(k6_standardize, dim3(B), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
-                       mu, std, N * A);
+    const size_t lds = (size_t)N * A * 3 * sizeof(float);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!force_streaming && lds <= 150 * 1024)
+        return ps_launch(k6_standardize_lds, dim3(B), dim3(1024), lds, s, xyz, atom_mask, mu, std, N * A);
+    return ps_launch(k6_standardize, dim3(B), dim3(1024), 0, s, xyz, atom_mask, mu, std, N * A);
+}
+
+extern "C" int ps_standardize_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std, int B, int N, int A,
+                                  void* stream) {
+    return standardize_dispatch(xyz, atom_mask, mu, std, B, N, A, false, stream);
+}
+
+extern "C" int ps_standardize_variant_f32(float* xyz, const uint8_t* atom_mask, float* mu, float* std, int B, int N,
+                                          int A, int variant, void* stream) {
+    if (variant != 0 && variant != 1) return (int)hipErrorInvalidValue;
+    return standardize_dispatch(xyz, atom_mask, mu, std, B, N, A, variant == 1, stream);
 }
 
 extern "C" int ps_affine_f32(float* xyz, const float* scale, const float* shift, int B, int n_atoms_per_struct,

@@ -1010,6 +1010,37 @@ def test_k6_golden_and_roundtrip(SB):
             sb.unstandardize()
 
 
+@pytest.mark.parametrize("B,N,A", [(256, 384, 15), (4, 100, 15), (3, 33, 5), (2, 853, 15), (2, 1000, 15), (5, 1, 15)])
+def test_k6_lds_resident_equals_streaming(SB, B, N, A):
+    """The LDS-resident standardize kernel (one read + one write of the coordinates; taken whenever a structure fits in
+    150 KB of LDS) against the three-sweep streaming kernel: mu, std and coordinates bit for bit, incl. structures that
+    do not start 16-byte aligned (N*A*3 odd), NaN atoms under the mask, the largest structure that still fits
+    (N=853) and one that does not (N=1000: both variants stream)."""
+    import ctypes
+    from protstruc_amd import _lib
+    lib = _lib.load()
+    xyz, mask = synth(600 + N, B, N, A=A, scale=9.0)
+    xyz[0, N // 2, A - 1] = float("nan")
+    mask[0, N // 2, A - 1] = False
+    outs = []
+    for variant in (0, 1):
+        x = xyz.clone().cuda()
+        m = mask.cuda().view(torch.uint8)
+        mu = torch.empty(B, 3, device="cuda")
+        sd = torch.empty(B, 3, device="cuda")
+        rc = lib.ps_standardize_variant_f32(x.data_ptr(), m.data_ptr(), mu.data_ptr(), sd.data_ptr(), B, N, A, variant,
+                                            torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert rc == 0
+        outs.append((x, mu, sd))
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(3.0), b.nan_to_num(3.0))
+    assert same(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    ref, rmu, rsd = O.standardize(xyz[:2], mask[:2])
+    assert_close(outs[0][1][:2], rmu, tol=3e-5)
+    assert_close(outs[0][0][:2], ref, tol=3e-5)
+    assert lib.ps_standardize_variant_f32(0, 0, 0, 0, B, N, A, 2, None) == 1
+
+
 def test_k6_batched_vs_oracle(SB):
     xyz, mask = synth(500, 16, 100, scale=12.0)
     xyz = xyz + torch.randn(16, 1, 1, 3) * 20
