@@ -176,7 +176,8 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
     from protstruc_amd import distributed as D
     from protstruc_amd import ops
 
-    b, n = (C4_B, C4_N) if not shared_gpu else (2, C4_N)   # ranks sharing one card (gloo rehearsal) cannot hold 151 GB each
+    # ranks sharing one card (gloo rehearsal on a 1-GPU box) cannot hold 151 GB each, and gloo moves data through the host
+    b, n = (C4_B, C4_N) if not shared_gpu else (2, C4_N // 2)
     xyz, mask = synth(1234, b, n)  # same seed on every rank: inputs are replicated, only outputs are sharded
     xyz, mask = xyz.to(dev), mask.to(dev)
     out_d = torch.empty(b, n, n, N_ATOM, N_ATOM, device=dev)
