@@ -714,7 +714,7 @@ struct FlatA {
     static constexpr int RPP = 256 / LPR;                                 // residues staged per pass
     static constexpr int RS = A <= 16 ? 16 : A;                           // float4 slots per staged residue
     static constexpr int SPL = (AA + 255) / 256;                          // slots per lane per group
-// pairs per chunk: 128 / 64 / 32 / 16 by atom count.  For 25 <= A <= 40 both neighbours were A/B-tested in one
+    // pairs per chunk: 128 / 64 / 32 / 16 by atom count.  For 25 <= A <= 40 both neighbours were A/B-tested in one
     // process against 32 (tools/k1_ab_libs.py, profiles/r02_k1_ab_chunk_length.log): 64 pairs 5.5-5.8 TB/s and 16 pairs
     // 5.1-5.4 against 5.9-6.3 (atom37 / A = 25)
     static constexpr int FL_LOG2 = A <= 16 ? 7 : (A <= 24 ? 6 : (A <= 40 ? 5 : 4));
