@@ -63,7 +63,7 @@ typedef struct ps_k1_config {
     int flat;             /* flat kernels: 0 never; 1 where they are the fast path (default); 2 force the A = 15 flat
                              pattern kernel; 3 force the any-A flat kernel; 4 force the fixed-A flat pattern kernel */
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1) */
-    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 */
+    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 8) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
     int jt;               /* pattern kernel: column residues per tile, 64 / 128, 0 = auto */

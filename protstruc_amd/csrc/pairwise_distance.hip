@@ -1641,6 +1641,9 @@ extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
     cfg->struct_size = (int)sizeof(ps_k1_config);
     cfg->flat = 1;
     cfg->rows_per_block = 1;
+    // 8 KB of idle LDS per workgroup of the pattern kernel (resident workgroups per CU 4 -> 3): with 1 row per workgroup
+    // the fastest configuration on every output buffer measured, fast or slow (profiles/r02_k1_ab_buffers.log)
+    cfg->lds_pad_kb = 8;
     cfg->flat_cpw = 1;
     cfg->xcd_remap = 1;
 }

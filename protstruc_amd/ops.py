@@ -102,25 +102,33 @@ def _on(device: torch.device):
     return _NO_SWITCH if device.index == torch.cuda.current_device() else torch.cuda.device(device)
 
 
-# ---- one-time, per-device choice of K1's output granule per workgroup ----------------------------------------
+# ---- optional, per-device choice of K1's output granule per workgroup -----------------------------------------
 # How fast K1's store stream is absorbed depends on the physical memory behind the output buffers (DESIGN.md,
-# "fast and slow allocations"): 2-4 residue rows per workgroup run at ~6.25 TB/s on some and at 4.9-5.4 TB/s on
-# others, while 1 row is 5.7-5.85 TB/s everywhere (profiles/r01_k1_box_survey.log); the flat kernel's chunks per
-# workgroup behaves the same way (+1-2 % / -8 %).  The first large call of each kind on a device therefore times
-# the candidates on the caller's own buffers (results are identical for every setting) and keeps the fastest for
-# that DEVICE: the choice is written to that device's entry of the host-side table in _lib.py and travels to the
-# library as a per-call argument, so other devices and threads are never affected.  Never runs during capture.
+# "fast and slow allocations").  With the correctly rounded square root of round 1 the best granule per workgroup
+# depended on the buffers too (2-4 residue rows per workgroup 6.25 TB/s on some, 4.9-5.4 on others), so the first
+# large call of a process timed the candidates on the caller's buffers.  With the hardware square root that spread is
+# gone: on eight buffers of one process -- two of the fast class, six of the slow one -- every configuration is within
+# 2 % of the best and ONE configuration (1 row per workgroup + 8 KB of idle LDS) is the fastest on every buffer
+# (tools/k1_ab_buffers.py, profiles/r02_k1_ab_buffers.log).  That configuration is therefore simply the default
+# (ps_k1_config_default), and nothing is timed behind the caller's back any more.  The tuner remains as an explicit
+# call -- ops.autotune_pairwise_distance(), which bench.py makes before its warm-up and reports -- or with
+# PROTSTRUC_AMD_AUTOTUNE=1 on the first large call of each kind per device; it writes that DEVICE's entry of the
+# host-side table in _lib.py (per-call argument to the library; other devices and threads are never affected) and
+# never runs during stream capture.
 _K1_TUNED = {}
 _K1_TUNE_LOCK = threading.Lock()
 # pattern kernel: (rows per workgroup, KB of idle LDS per workgroup).  The LDS pad only lowers the number of resident
-# workgroups per CU (4 -> 3): on slow allocations that is worth ~2 % (fewer concurrent streams).
-_K1_CANDIDATE_PATTERN = ((1, 0), (1, 8), (2, 0), (4, 0))
+# workgroups per CU (4 -> 3: fewer concurrent streams).  The default (1 row + 8 KB) comes first: the choice moves away
+# from it only for a clear (>= 1.5 %) gain.
+_K1_CANDIDATE_PATTERN = ((1, 8), (1, 0), (2, 0), (4, 0))
 _K1_CANDIDATE_FLAT = ((1, 0), (1, 8), (2, 0), (4, 0))   # flat kernel: (chunks per workgroup, KB of idle LDS)
 
 
-def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
+def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False) -> None:
     import os
 
+    if not force and not os.environ.get("PROTSTRUC_AMD_AUTOTUNE"):
+        return
     if A != 15 or N < 16 or n_pairs < (1 << 22):
         return
     # which kernel this shape takes decides which knob is tuned (pairwise_distance.hip: flat_eligible)
@@ -128,7 +136,7 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int) -> None:
     result_key = "rows_per_block" if pattern else "flat_cpw"
     if result_key in _K1_TUNED.get(device, {}):
         return
-    if os.environ.get("PROTSTRUC_AMD_NO_AUTOTUNE") or torch.cuda.is_current_stream_capturing():
+    if torch.cuda.is_current_stream_capturing():
         return
     if not pattern and (_lib.get_tuning("k1_flat", device) == 0 or _lib.get_tuning("k1_variant", device) != 0):
         return
@@ -190,8 +198,10 @@ def get_exact_sqrt(device=None) -> bool:
 
 def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,
                                out_mask: torch.Tensor):
-    """Run the one-time per-device K1 autotune now (library initialisation), on the given buffers."""
-    pairwise_distance(xyz, atom_mask, out_dist=out_dist, out_mask=out_mask)
+    """Time K1's launch configurations on the given buffers now and keep the fastest for this device (results are
+    identical for every configuration).  Optional: the default configuration is already the one that was fastest on
+    every buffer measured."""
+    pairwise_distance(xyz, atom_mask, out_dist=out_dist, out_mask=out_mask, _autotune=True)
     torch.cuda.current_stream(xyz.device).synchronize()
     return k1_autotune_result(xyz.device)
 
@@ -214,7 +224,7 @@ def allocate_fast_outputs(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] =
         for _ in range(max(1, int(candidates))):
             pairs.append((torch.empty(shape, dtype=torch.float32, device=xyz.device),
                           torch.empty(shape, dtype=torch.bool, device=xyz.device)))
-        pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])   # autotune + warm-up
+        pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])   # warm-up
         t_end = time.perf_counter() + 0.12
         while time.perf_counter() < t_end:
             pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])
@@ -246,7 +256,8 @@ def k1_autotune_result(device=None):
 def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *,
                       row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
                       out_dist: Optional[torch.Tensor] = None, out_mask: Optional[torch.Tensor] = None,
-                      want_dist: bool = True, want_mask: bool = True) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+                      want_dist: bool = True, want_mask: bool = True,
+                      _autotune: bool = False) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
     """K1.  Returns (dist fp32, dist_mask bool) of shape (B, rows, N, A, A).
 
     rows = N for the default full matrix.  With ``row_begin/row_end`` only those
@@ -273,7 +284,7 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
             if dmask.shape != shape or dmask.dtype != torch.bool or not dmask.is_contiguous():
                 raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
         args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
-        _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A)
+        _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A, force=_autotune)
         cfg = _lib.k1_config(xyz.device)   # this device's settings, snapshotted for this launch
         rc = 0
         if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)

@@ -5,7 +5,7 @@ plus the default dispatch with only the distance plane / only the mask plane.
 Arguments: key=value K1 tuning applied to every run (e.g. flat_cpw=2), `json=path` writes the table."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # no implicit tuning while measuring
 import torch
 from protstruc_amd import _lib, ops
 out_json = None

@@ -3,7 +3,7 @@
 usage: k1_ab.py "variant=0,jt=64,rows_per_block=1,unroll=0" "variant=0,jt=64,rows_per_block=1,unroll=1" ..."""
 import os, sys, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["PROTSTRUC_AMD_NO_AUTOTUNE"] = "1"   # this harness sets every knob itself
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # this harness sets every knob itself
 import torch
 from protstruc_amd import _lib, ops
 B, N, A = int(os.environ.get("K1_B", "64")), int(os.environ.get("K1_N", "512")), 15

@@ -1,0 +1,57 @@
+#!/usr/bin/python3
+"""Which K1 launch configuration is fastest on WHICH output buffer?  Allocates several output-buffer pairs of the
+headline shape in one process (they land in physical memory of different "speed classes") and
+times a list of configurations on each, interleaved.  Informs the autotuner's candidate list; results are identical
+for every configuration.  Usage: python3 tools/k1_ab_buffers.py [n_buffers]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)
+import torch
+
+from protstruc_amd import _lib, ops
+
+nbuf = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+B, N, A = 64, 512, 15
+g = torch.Generator().manual_seed(0)
+xyz = torch.randn(B, N, A, 3, generator=g).cuda()
+mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
+cfgs = {
+    "r1 jt128": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=0, k1_flat=1),
+    "r1 jt64": dict(k1_rows_per_block=1, k1_jt=64, k1_lds_pad_kb=0, k1_flat=1),
+    "r1 jt128 +8KB": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=8, k1_flat=1),
+    "r1 jt64 +8KB": dict(k1_rows_per_block=1, k1_jt=64, k1_lds_pad_kb=8, k1_flat=1),
+    "r2 jt128": dict(k1_rows_per_block=2, k1_jt=128, k1_lds_pad_kb=0, k1_flat=1),
+    "r2 jt64": dict(k1_rows_per_block=2, k1_jt=64, k1_lds_pad_kb=0, k1_flat=1),
+    "r4 jt64": dict(k1_rows_per_block=4, k1_jt=64, k1_lds_pad_kb=0, k1_flat=1),
+    "flat": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=0, k1_flat=2),
+}
+bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
+        for _ in range(nbuf)]
+
+
+def apply(c):
+    for k, v in c.items():
+        _lib.set_tuning(k, v)
+
+
+for _ in range(30):
+    ops.pairwise_distance(xyz, mask, out_dist=bufs[0][0], out_mask=bufs[0][1])
+torch.cuda.synchronize()
+best = {(n, k): float("inf") for n in cfgs for k in range(nbuf)}
+for rnd in range(3):
+    for k, (d, m) in enumerate(bufs):
+        for name, c in cfgs.items():
+            apply(c)
+            ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m)
+            e1.record(); torch.cuda.synchronize()
+            best[(name, k)] = min(best[(name, k)], e0.elapsed_time(e1) / 3)
+nb = B * N * N * A * A * 5
+print(f"{'config':16s}" + "".join(f"  buf{k}" for k in range(nbuf)) + "   (TB/s)")
+for name in cfgs:
+    print(f"{name:16s}" + "".join(f" {nb / best[(name, k)] / 1e9:5.2f}" for k in range(nbuf)), flush=True)

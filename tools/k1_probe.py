@@ -5,7 +5,7 @@ import sys
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os
-os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # no implicit tuning while measuring
 import torch
 from protstruc_amd import _lib, ops
 

@@ -7,7 +7,7 @@ m = 0: correctly rounded sqrt, 1: hardware sqrt (product default), 2: store-only
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os
-os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # no implicit tuning while measuring
 import torch
 from protstruc_amd import _lib, ops
 B, N, A = 64, 512, 15

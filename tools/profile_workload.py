@@ -11,7 +11,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("PROTSTRUC_AMD_NO_AUTOTUNE", "1")
+os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # no implicit tuning while measuring
 import torch
 
 from protstruc_amd import StructureBatch, _lib, ops
