@@ -117,11 +117,32 @@ def _on(device: torch.device):
 # never runs during stream capture.
 _K1_TUNED = {}
 _K1_TUNE_LOCK = threading.Lock()
-# pattern kernel: (rows per workgroup, KB of idle LDS per workgroup).  The LDS pad only lowers the number of resident
-# workgroups per CU (4 -> 3: fewer concurrent streams).  The default (1 row + 8 KB) comes first: the choice moves away
-# from it only for a clear (>= 1.5 %) gain.
-_K1_CANDIDATE_PATTERN = ((1, 8), (1, 0), (2, 0), (4, 0))
-_K1_CANDIDATE_FLAT = ((1, 0), (1, 8), (2, 0), (4, 0))   # flat kernel: (chunks per workgroup, KB of idle LDS)
+# Candidates of the explicit tuner, as ps_k1_config fields.  The default comes first: the choice moves away from it
+# only for a clear (>= 1.5 %) gain.  Pattern kernel (N % 16 == 0): rows per workgroup, KB of idle LDS per workgroup
+# (only lowers the number of resident workgroups per CU: fewer concurrent store streams) and column residues per
+# tile.  What the second measurement on 6 + 8 buffers showed (profiles/r02_k1_ab_buffers.log): fast buffers like the
+# 64-residue tile + 8 KB best (7.1-7.2 TB/s against 7.0), slow buffers a hard cap of 2 workgroups per CU (64-residue
+# tile + 36 KB: 6.1 TB/s on EVERY buffer, against 5.9-6.0 for everything else on a slow one and 7.0+ on a fast one).
+_K1_CANDIDATE_PATTERN = (
+    {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 0},
+    {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 64},
+    {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 64},
+    {"rows_per_block": 1, "lds_pad_kb": 0, "jt": 0},
+    {"rows_per_block": 2, "lds_pad_kb": 0, "jt": 0},
+)
+# flat kernel (any other N >= 16): chunks per workgroup, KB of idle LDS
+_K1_CANDIDATE_FLAT = (
+    {"flat_cpw": 1, "flat_lds_pad_kb": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 8},
+    {"flat_cpw": 2, "flat_lds_pad_kb": 0},
+    {"flat_cpw": 4, "flat_lds_pad_kb": 0},
+)
+
+
+def _cand_label(c) -> str:
+    if "rows_per_block" in c:
+        return f"{c['rows_per_block']}row" + (f"+{c['lds_pad_kb']}KB" if c["lds_pad_kb"] else "") + (f" jt{c['jt']}" if c["jt"] else "")
+    return f"{c['flat_cpw']}chunk" + (f"+{c['flat_lds_pad_kb']}KB" if c["flat_lds_pad_kb"] else "")
 
 
 def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False) -> None:
@@ -146,43 +167,39 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False
         lib = _lib.load()
         stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
         candidates = _K1_CANDIDATE_PATTERN if pattern else _K1_CANDIDATE_FLAT
-        fields = ("rows_per_block", "lds_pad_kb") if pattern else ("flat_cpw", "flat_lds_pad_kb")
         # one private configuration struct per candidate: nothing shared is touched while timing
-        cfgs = {c: _lib.k1_config(device, **dict(zip(fields, c))) for c in candidates}
+        cfgs = [_lib.k1_config(device, **c) for c in candidates]
 
-        def launch(cand):
-            _lib.check(lib.ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfgs[cand]), stream),
+        def launch(k):
+            _lib.check(lib.ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfgs[k]), stream),
                        "ps_pairwise_distance_cfg_f32 (autotune)")
 
         # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
         # then time the candidates in interleaved rounds and keep each one's minimum
         t_end = time.perf_counter() + 0.12
         while time.perf_counter() < t_end:
-            launch(candidates[0])
+            launch(0)
             torch.cuda.current_stream(device).synchronize()
-        timings = {c: float("inf") for c in candidates}
+        timings = [float("inf")] * len(candidates)
         for _ in range(3):
-            for c in candidates:
-                launch(c)
+            for k in range(len(candidates)):
+                launch(k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                launch(c)
-                launch(c)
+                launch(k)
+                launch(k)
                 e1.record()
                 e1.synchronize()
-                timings[c] = min(timings[c], e0.elapsed_time(e1) / 2)
-        best, best_ms = candidates[0], timings[candidates[0]]
-        for c in candidates[1:]:
-            if timings[c] < best_ms * 0.985:   # prefer the earlier (smaller-granule) candidate unless the gain is clear
-                best, best_ms = c, timings[c]
-        _lib.set_tuning("k1_" + fields[0], best[0], device)
-        _lib.set_tuning("k1_" + fields[1], best[1], device)
-        label = {c: (c[0] if c[1] == 0 else f"{c[0]}+{c[1]}KB") for c in candidates}
-        ms = {label[c]: timings[c] for c in candidates}
-        if pattern:
-            _K1_TUNED.setdefault(device, {}).update({"rows_per_block": best[0], "lds_pad_kb": best[1], "ms": ms})
-        else:
-            _K1_TUNED.setdefault(device, {}).update({"flat_cpw": best[0], "flat_lds_pad_kb": best[1], "flat_ms": ms})
+                timings[k] = min(timings[k], e0.elapsed_time(e1) / 2)
+        best = 0
+        for k in range(1, len(candidates)):
+            if timings[k] < timings[best] * 0.985:   # prefer the earlier candidate unless the gain is clear
+                best = k
+        for field, value in candidates[best].items():
+            _lib.set_tuning("k1_" + field, value, device)
+        report = dict(candidates[best])
+        report["flat_ms" if not pattern else "ms"] = {_cand_label(c): timings[k] for k, c in enumerate(candidates)}
+        _K1_TUNED.setdefault(device, {}).update(report)
 
 
 def set_exact_sqrt(flag: bool, device=None) -> None:

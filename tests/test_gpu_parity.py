@@ -538,9 +538,10 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         assert ops.k1_autotune_result(xg.device) is None, "an ordinary call must not tune"
         out_d, out_m = torch.empty_like(d0), torch.empty_like(m0)
         res = ops.autotune_pairwise_distance(xg, mg, out_d, out_m)
-        assert res is not None and res["rows_per_block"] in (1, 2, 4) and set(res["ms"]) == {1, "1+8KB", 2, 4}
+        assert res is not None and res["rows_per_block"] in (1, 2)
+        assert set(res["ms"]) == {ops._cand_label(c) for c in ops._K1_CANDIDATE_PATTERN} and len(res["ms"]) == 5
         assert _lib.get_tuning("k1_rows_per_block") == res["rows_per_block"]
-        assert _lib.get_tuning("k1_lds_pad_kb") == res["lds_pad_kb"]
+        assert _lib.get_tuning("k1_lds_pad_kb") == res["lds_pad_kb"] and _lib.get_tuning("k1_jt") == res["jt"]
         assert torch.equal(out_d, d0) and torch.equal(out_m, m0)
         d1, m1 = ops.pairwise_distance(xg, mg)
         assert torch.equal(d0, d1) and torch.equal(m0, m1)
@@ -567,7 +568,8 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         assert torch.equal(e0, e1) and torch.equal(f0, f1)
     finally:
         os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)
-        for k, v in (("k1_rows_per_block", rows0), ("k1_lds_pad_kb", pad0), ("k1_flat_cpw", 1), ("k1_flat_lds_pad_kb", 0)):
+        for k, v in (("k1_rows_per_block", rows0), ("k1_lds_pad_kb", pad0), ("k1_jt", 0), ("k1_flat_cpw", 1),
+                     ("k1_flat_lds_pad_kb", 0)):
             _lib.set_tuning(k, v)
         ops._K1_TUNED.pop(xg.device, None)
         if saved_tuned is not None:

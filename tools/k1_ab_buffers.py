@@ -26,6 +26,10 @@ cfgs = {
     "r2 jt64": dict(k1_rows_per_block=2, k1_jt=64, k1_lds_pad_kb=0, k1_flat=1),
     "r4 jt64": dict(k1_rows_per_block=4, k1_jt=64, k1_lds_pad_kb=0, k1_flat=1),
     "flat": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=0, k1_flat=2),
+    # stronger residency caps: 36 KB + pad of LDS per workgroup -> 2 workgroups per CU from 18 KB, 1 from 45 KB
+    "r1 jt128 +20KB": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=20, k1_flat=1),
+    "r1 jt128 +48KB": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=48, k1_flat=1),
+    "r1 jt64 +36KB": dict(k1_rows_per_block=1, k1_jt=64, k1_lds_pad_kb=36, k1_flat=1),
 }
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
         for _ in range(nbuf)]
