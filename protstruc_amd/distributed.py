@@ -44,7 +44,10 @@ _COMMS = {}
 
 
 def _group_key(group):
-    return "WORLD" if group is None or group is dist.group.WORLD else id(group)
+    """Identity of a process group that does not survive destroy_process_group() + init_process_group(): the name
+    torch gives every group it creates is unique within the process (a counter), the object id guards the rest."""
+    pg = dist.group.WORLD if group is None else group
+    return (getattr(pg, "group_name", None), id(pg))
 
 
 def native_comm(group=None):
@@ -54,7 +57,7 @@ def native_comm(group=None):
 
     key = _group_key(group)
     if key in _COMMS:
-        return _COMMS[key]
+        return _COMMS[key][0]
     lib = _rccl.load()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     ident = [None]
@@ -67,7 +70,8 @@ def native_comm(group=None):
     comm = ctypes.c_void_p()
     idbuf = ctypes.create_string_buffer(ident[0], _rccl.COMM_ID_BYTES)
     _rccl.check(lib.ps_comm_create(ctypes.byref(comm), idbuf, world, rank), "ps_comm_create")
-    _COMMS[key] = comm
+    # the group object is kept alongside: while this entry exists its id cannot be reused by a later group
+    _COMMS[key] = (comm, dist.group.WORLD if group is None else group)
     return comm
 
 
@@ -76,7 +80,7 @@ def destroy_native_comms() -> None:
     from . import _rccl
 
     while _COMMS:
-        _, comm = _COMMS.popitem()
+        _, (comm, _pg) = _COMMS.popitem()
         _rccl.check(_rccl.load().ps_comm_destroy(comm), "ps_comm_destroy")
 
 
