@@ -128,7 +128,27 @@ def build_rccl(force=False, verbose=True):
     return RCCL_LIB_PATH
 
 
+EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "c_abi_demo.c")
+EXAMPLE_BIN = os.path.join(HERE, "..", "build", "c_abi_demo")
+
+
+def build_c_example(verbose=True):
+    """examples/c_abi_demo.c with plain gcc -std=c99: proves that include/protstruc_hip.h is a C header and that the
+    boundary needs neither C++ nor PyTorch on the caller's side.  The binary is a GPU test (tests/test_c_abi_from_c.py)."""
+    os.makedirs(os.path.dirname(EXAMPLE_BIN), exist_ok=True)
+    rocm_inc = os.path.join(os.path.dirname(ROCM_LIB.rstrip("/")), "include")
+    cmd = ["gcc", "-std=c99", "-O1", "-ffp-contract=off", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__",
+           "-I" + rocm_inc, "-I" + os.path.join(HERE, "..", "include"), EXAMPLE_SRC,
+           "-L" + LIB_DIR, "-lprotstruc_hip", "-L" + ROCM_LIB, "-lamdhip64", "-lm",
+           "-Wl,-rpath,$ORIGIN/../protstruc_amd/lib", "-Wl,-rpath," + ROCM_LIB, "-o", EXAMPLE_BIN]
+    if verbose:
+        print("[protstruc_amd.build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return EXAMPLE_BIN
+
+
 if __name__ == "__main__":
     force = "--force" in sys.argv
     print(build(force=force, experiments="--experiments" in sys.argv))
     print(build_rccl(force=force))
+    print(build_c_example())

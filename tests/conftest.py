@@ -44,6 +44,13 @@ def pytest_sessionstart(session):
         log = open(os.path.join(outdir, name + ".log"), "w")
         proc = subprocess.Popen([sys.executable, script, "--out", out] + extra, stdout=log, stderr=subprocess.STDOUT)
         REHEARSALS[name] = {"proc": proc, "out": out, "log": log.name}
+    # the plain-C consumer of the C ABI (examples/c_abi_demo.c): compiled with gcc and run as its own process
+    log = open(os.path.join(outdir, "c_abi_demo.log"), "w")
+    code = ("import sys, subprocess; sys.path.insert(0, %r); from protstruc_amd import build; "
+            "build.build(verbose=False); exe = build.build_c_example(verbose=False); "
+            "sys.exit(subprocess.run([exe]).returncode)" % ROOT)
+    proc = subprocess.Popen([sys.executable, "-c", code], stdout=log, stderr=subprocess.STDOUT)
+    REHEARSALS["c_abi_demo"] = {"proc": proc, "out": None, "log": log.name}
 
 
 def pytest_sessionfinish(session, exitstatus):

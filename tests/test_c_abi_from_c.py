@@ -1,0 +1,31 @@
+"""The drop-in boundary from plain C: examples/c_abi_demo.c is compiled with `gcc -std=c99 -Wall -Werror` against
+include/protstruc_hip.h (CPU test: the header is a C header and every symbol links) and run on the GPU box as its own
+process, where it checks distances (1 ulp with the hardware square root, bit-exact with exact_sqrt), the pair mask,
+frames and the argument-error convention without Python or PyTorch on the caller's side."""
+import os
+
+import pytest
+
+from tests import conftest
+
+
+def test_c99_consumer_compiles_and_links():
+    from protstruc_amd import build
+    build.build(force=False, verbose=False)
+    exe = build.build_c_example(verbose=False)
+    assert os.path.exists(exe) and os.access(exe, os.X_OK)
+
+
+@pytest.mark.gpu
+def test_c99_consumer_runs_on_the_gpu():
+    if "c_abi_demo" not in conftest.REHEARSALS:
+        pytest.fail("the C demo was not started (conftest.pytest_sessionstart found no GPU?)")
+    r = conftest.REHEARSALS["c_abi_demo"]
+    try:
+        code = r["proc"].wait(timeout=300)
+    except Exception:  # noqa: BLE001
+        r["proc"].kill()
+        pytest.fail("c_abi_demo did not finish; log:\n" + open(r["log"]).read()[-2000:])
+    log = open(r["log"]).read()
+    assert code == 0 and "c_abi_demo ok" in log, log[-2000:]
+    assert "exact_sqrt=1" in log and "(0 one ulp off)" in log
