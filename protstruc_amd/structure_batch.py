@@ -232,6 +232,20 @@ class StructureBatch:
             dmask = dmask.to(self.atom_mask.dtype)  # Q7: mask dtype follows atom_mask
         return dist, dmask
 
+    def pairwise_distance_matrix_sharded(self, group=None, gather=True, impl=None):
+        """Multi-GPU form of :meth:`pairwise_distance_matrix` (one process per GPU, ``torch.distributed`` initialised;
+        every rank holds the same batch): this rank computes residue rows [lo, hi) = its share of N straight into a
+        full-size buffer; ``gather=True`` reassembles the whole matrix on every rank (RCCL all-gather over xGMI),
+        ``gather=False`` leaves the row-sharded result, ``gather="recompute"`` computes everything locally with no
+        collective.  Returns ``(dist, dist_mask, (lo, hi))``; see ``protstruc_amd.distributed``."""
+        from . import distributed
+
+        dist, dmask, rows = distributed.pairwise_distance_matrix_sharded(self.xyz, self.atom_mask, group=group,
+                                                                        gather=gather, impl=impl)
+        if self.atom_mask is not None and self.atom_mask.dtype != torch.bool:
+            dmask = dmask.to(self.atom_mask.dtype)
+        return dist, dmask, rows
+
     # ------------------------------------------------------------------ A3 backbone dihedrals
     def backbone_dihedrals(self) -> Tuple[torch.FloatTensor, torch.BoolTensor]:
         """phi, psi, omega per residue and their validity mask (protstruc.py:486-541)."""
@@ -280,6 +294,20 @@ class StructureBatch:
         """Planar angle of the three points (protstruc.py:642-660)."""
         si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
         return ops.pairwise_angles(self.xyz, si, sj, 3)
+
+    def pairwise_dihedrals_sharded(self, atoms_i: List[str], atoms_j: List[str], group=None, gather=True, impl=None):
+        """Row-sharded :meth:`pairwise_dihedrals` (see :meth:`pairwise_distance_matrix_sharded`).  Returns ``(out, (lo, hi))``."""
+        from . import distributed
+
+        si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
+        return distributed.pairwise_angles_sharded(self.xyz, si, sj, 4, group=group, gather=gather, impl=impl)
+
+    def pairwise_planar_angles_sharded(self, atoms_i: List[str], atoms_j: List[str], group=None, gather=True, impl=None):
+        """Row-sharded :meth:`pairwise_planar_angles`.  Returns ``(out, (lo, hi))``."""
+        from . import distributed
+
+        si, sj = self._pairwise_atom_slots(atoms_i, atoms_j)
+        return distributed.pairwise_angles_sharded(self.xyz, si, sj, 3, group=group, gather=gather, impl=impl)
 
     def inter_residue_geometry(self) -> Dict[str, torch.Tensor]:
         """trRosetta-style inter-residue features (protstruc.py:790-817)."""

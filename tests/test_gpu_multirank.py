@@ -46,6 +46,7 @@ def test_two_ranks_gloo_real_kernels_bit_identical():
     ns = {c["N"] for r in s["ranks"] for c in r["cases"]}
     assert any(n % 2 == 0 for n in ns) and any(n % 2 == 1 for n in ns)
     assert s["n_cases"] >= 2 * 30
+    assert any(c["op"] == "StructureBatch.*_sharded" and c["ok"] for r in s["ranks"] for c in r["cases"])
 
 
 def test_one_rank_rccl_native_gather():

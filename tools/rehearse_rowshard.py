@@ -82,6 +82,21 @@ def rank_main(args):
                             ok = same(a[:, lo:hi], want[:, lo:hi]) and bool((a[:, outside] == 77.0).all())
                         results.append({"op": f"angles{npts}", "B": B, "N": N, "gather": str(gather), "ok": bool(ok)})
                         ok_all &= bool(ok)
+        # the same through the StructureBatch methods
+        from protstruc_amd import StructureBatch
+        g = torch.Generator().manual_seed(77)
+        xyz = torch.randn(2, 34, 15, 3, generator=g)
+        mask = torch.rand(2, 34, 15, generator=g) < 0.9
+        sb = StructureBatch.from_xyz(xyz, mask, device=dev)
+        want_d, want_m = sb.pairwise_distance_matrix()
+        d, m, _ = sb.pairwise_distance_matrix_sharded(gather=True)
+        om, _ = sb.pairwise_dihedrals_sharded(["CA", "CB"], ["CA", "CB"], gather=True)
+        ph, _ = sb.pairwise_planar_angles_sharded(["CA", "CB"], ["CB"], gather=True)
+        torch.cuda.synchronize(dev)
+        ok = (same(d, want_d) and torch.equal(m, want_m) and same(om, sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]))
+              and same(ph, sb.pairwise_planar_angles(["CA", "CB"], ["CB"])))
+        results.append({"op": "StructureBatch.*_sharded", "B": 2, "N": 34, "gather": "True", "ok": bool(ok)})
+        ok_all &= bool(ok)
         dist.barrier()
     finally:
         D.destroy_native_comms()
