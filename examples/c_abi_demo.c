@@ -5,8 +5,9 @@
  *       -Lprotstruc_amd/lib -lprotstruc_hip -L/opt/rocm/lib -lamdhip64 -lm \
  *       -Wl,-rpath,$PWD/protstruc_amd/lib -Wl,-rpath,/opt/rocm/lib -o build/c_abi_demo
  *
- * Allocates with hipMalloc, calls ps_pairwise_distance_f32 / ps_pairwise_distance_cfg_f32 / ps_backbone_dihedrals_f32 /
- * ps_frames_f32 on a stream of its own, and checks the results on the host: distances against the float formula
+ * Allocates with hipMalloc, calls ps_pairwise_distance_f32 / ps_pairwise_distance_cfg_f32 / ps_frames_f32 /
+ * ps_diffuse_f32 on a stream of its own (the last two also captured into a hipGraph and replayed), and checks the
+ * results on the host: distances against the float formula
  * sqrtf((dx*dx + dy*dy) + dz*dz) -- within 1 ulp with the default hardware square root, bit for bit with
  * ps_k1_config.exact_sqrt = 1 -- the pair mask exactly, frames for orthonormality.  Exit code 0 = all checks passed.
  * (Replaces, for a C host, what StructureBatch.pairwise_distance_matrix does in the reference: protstruc.py:455-484.)
@@ -117,6 +118,57 @@ int main(void) {
         if (memcmp(tr + (size_t)r * 3, xyz + ((size_t)r * A + 1) * 3, 12) != 0) { fprintf(stderr, "translation %d\n", r); return 9; }
     }
     printf("frames: %d orthonormal, translations exact\n", B * N);
+
+    /* The diffusion loop of BASELINE config 5 in miniature, captured into a hipGraph from C: T steps of
+     * ps_diffuse_f32 + ps_frames_f32 (reference protstruc.py:864-878, :543-571).  The launchers allocate nothing and
+     * never synchronise, so they are legal inside stream capture; the draw counter lives on the device and is advanced
+     * by the kernels themselves, so every replay continues the noise stream. */
+    {
+        enum { T = 10 };
+        uint64_t h_state[PS_RNG_STATE_WORDS];
+        memset(h_state, 0, sizeof h_state);
+        h_state[0] = 1234;   /* seed; word 1 = draw counter; the rest are the kernels' tickets (zero between launches) */
+        uint64_t* d_state;
+        float* d_beta;
+        float h_beta[B] = {0.05f, 0.2f};
+        CK(hipMalloc((void**)&d_state, sizeof h_state));
+        CK(hipMalloc((void**)&d_beta, sizeof h_beta));
+        CK(hipMemcpy(d_state, h_state, sizeof h_state, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_beta, h_beta, sizeof h_beta, hipMemcpyHostToDevice));
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        CK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        for (int t = 0; t < T; ++t) {
+            PS(ps_diffuse_f32(d_xyz, d_beta, B, N * A * 3, d_state, NULL, stream));
+            PS(ps_frames_f32(d_xyz, d_rot, d_trans, B, N, A, 0, 1, 2, 1, stream));
+        }
+        CK(hipStreamEndCapture(stream, &graph));
+        CK(hipGraphInstantiate(&exec, graph, NULL, NULL, 0));
+        float* x1 = malloc(n_xyz * 4);
+        float* x2 = malloc(n_xyz * 4);
+        CK(hipGraphLaunch(exec, stream));
+        CK(hipStreamSynchronize(stream));
+        CK(hipMemcpy(x1, d_xyz, n_xyz * 4, hipMemcpyDeviceToHost));
+        CK(hipGraphLaunch(exec, stream));
+        CK(hipStreamSynchronize(stream));
+        CK(hipMemcpy(x2, d_xyz, n_xyz * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h_state, d_state, sizeof h_state, hipMemcpyDeviceToHost));
+        if (h_state[1] != 2 * T) { fprintf(stderr, "draw counter %llu, want %d\n", (unsigned long long)h_state[1], 2 * T); return 11; }
+        for (int w = 2; w < PS_RNG_STATE_WORDS; ++w)
+            if (h_state[w] != 0) { fprintf(stderr, "ticket word %d not reset\n", w); return 11; }
+        if (memcmp(x1, x2, n_xyz * 4) == 0 || memcmp(x1, xyz, n_xyz * 4) == 0) { fprintf(stderr, "replay did not draw fresh noise\n"); return 11; }
+        /* after 20 steps at beta 0.05 / 0.2 the coordinates are a mix of data and unit-variance noise: finite, moved */
+        for (size_t i = 0; i < n_xyz; ++i)
+            if (!(x2[i] == x2[i]) || fabsf(x2[i]) > 50.f) { fprintf(stderr, "coordinate %zu = %g\n", i, x2[i]); return 11; }
+        CK(hipMemcpy(rot, d_rot, (size_t)B * N * 9 * 4, hipMemcpyDeviceToHost));
+        for (int r = 0; r < B * N; ++r) {
+            const float* R = rot + (size_t)r * 9;
+            const float n0 = R[0] * R[0] + R[3] * R[3] + R[6] * R[6];
+            if (fabsf(n0 - 1.f) > 2e-5f) { fprintf(stderr, "captured frame %d not unit\n", r); return 11; }
+        }
+        printf("hipGraph: %d captured steps replayed twice, draw counter %llu, fresh noise per replay\n", T, (unsigned long long)h_state[1]);
+        hipGraphExecDestroy(exec); hipGraphDestroy(graph); hipFree(d_state); hipFree(d_beta); free(x1); free(x2);
+    }
 
     /* argument errors come back as hipErrorInvalidValue before anything is launched */
     if (ps_pairwise_distance_f32(NULL, d_mask, d_dist, d_dmask, B, N, A, 0, N, N, 0, stream) != 1) return 10;

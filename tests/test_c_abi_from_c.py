@@ -29,3 +29,4 @@ def test_c99_consumer_runs_on_the_gpu():
     log = open(r["log"]).read()
     assert code == 0 and "c_abi_demo ok" in log, log[-2000:]
     assert "exact_sqrt=1" in log and "(0 one ulp off)" in log
+    assert "hipGraph: 10 captured steps replayed twice, draw counter 20" in log
