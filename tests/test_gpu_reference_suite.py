@@ -1,0 +1,266 @@
+"""The reference's own test scenarios (dohlee/protstruc tests/test_StructureBatch.py, tests/test_geometry.py), restated
+against `protstruc_amd` on the GPU -- one test here per test there, same name after the `test_`, same assertions.
+Where the reference downloads an entry (`from_pdb_id("1REX")`, network) the same scenario runs on the PDB fixtures the
+reference ships (`tests/golden/15c8_HL.pdb`: 229 residues, `1ad0_DC.pdb`: 434), so the expected sizes are those files'.
+Citations: reference tests/test_StructureBatch.py:LINE, tests/test_geometry.py:LINE."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ONE = os.path.join(G, "15c8_HL.pdb")          # 229 residues, chains L + H
+TWO = [ONE, os.path.join(G, "1ad0_DC.pdb")]   # 229 and 434 residues
+
+
+@pytest.fixture(scope="module")
+def ps():
+    assert torch.cuda.is_available()
+    import protstruc_amd
+    import protstruc_amd.geometry as geom
+    from protstruc_amd.general import ATOM
+    return protstruc_amd.StructureBatch, geom, ATOM
+
+
+# ---------------------------------------------------------------- tests/test_StructureBatch.py
+def test_StructureBatch_from_xyz(ps):                                   # :10
+    SB = ps[0]
+    sb = SB.from_xyz(np.random.rand(16, 100, 25, 3))
+    assert sb.get_max_n_residues() == 100 and sb.get_batch_size() == 16
+
+
+def test_max_n_atoms_per_residue(ps):                                   # :16
+    sb = ps[0].from_xyz(np.random.rand(16, 100, 25, 3))
+    assert sb.get_max_n_atoms_per_residue() == 25
+
+
+def test_StructureBatch_from_xyz_with_chain_ids(ps):                    # :24
+    chain_idx = np.zeros((16, 100))
+    chain_idx[:, 20:60] = 1.0
+    chain_idx[:, 60:] = 2.0
+    sb = ps[0].from_xyz(np.random.rand(16, 100, 25, 3), chain_idx=chain_idx, chain_ids=[["A", "B", "C"]] * 16)
+    assert sb.get_n_terminal_mask().shape == (16, 100) and sb.get_c_terminal_mask().shape == (16, 100)
+    assert (sb.get_n_terminal_mask().sum(axis=1) == 3).all() and (sb.get_c_terminal_mask().sum(axis=1) == 3).all()
+
+
+def test_StructureBatch_from_pdb_single(ps):                            # :43
+    sb = ps[0].from_pdb(TWO[1])
+    assert len(sb.get_xyz()) == 1
+    assert (sb.get_n_terminal_mask().sum(axis=1) == 2).all() and (sb.get_c_terminal_mask().sum(axis=1) == 2).all()
+
+
+def test_StructureBatch_from_pdb_multiple(ps):                          # :56
+    sb = ps[0].from_pdb(TWO + [os.path.join(G, "5cjx_HL.pdb")])
+    assert len(sb.get_xyz()) == 3
+    assert (sb.get_n_terminal_mask().sum(axis=1) == 2).all() and (sb.get_c_terminal_mask().sum(axis=1) == 2).all()
+
+
+def test_StructureBatch_backbone_dihedrals(ps):                         # :68
+    chain_idx = np.zeros((16, 100))
+    chain_idx[:, 20:60] = 1.0
+    chain_idx[:, 60:] = 2.0
+    sb = ps[0].from_xyz(np.random.rand(16, 100, 25, 3), chain_idx=chain_idx, chain_ids=[["A", "B", "C"]] * 16)
+    dihedrals, dihedral_mask = sb.backbone_dihedrals()
+    assert dihedrals.shape == (16, 100, 3) and dihedral_mask.shape == (16, 100, 3)
+    assert ((dihedrals >= -math.pi) & (dihedrals <= math.pi)).all()
+    assert ((dihedrals >= -math.pi) & (dihedrals < 0)).any() and ((dihedrals >= 0) & (dihedrals <= math.pi)).any()
+    nterm, cterm = sb.get_n_terminal_mask(), sb.get_c_terminal_mask()
+    assert (dihedrals[nterm][:, 0] == 0.0).all()           # phi is undefined at an N-terminus: zero-filled
+    assert (dihedrals[cterm][:, [1, 2]] == 0.0).all()      # psi and omega at a C-terminus
+
+
+def test_StructureBatch_pairwise_distance_matrix(ps):                   # :122
+    SB, _, ATOM = ps
+    sb = SB.from_pdb(ONE)
+    dist, dist_mask = sb.pairwise_distance_matrix()
+    assert dist.shape == (1, 229, 229, 15, 15) and dist_mask.shape == (1, 229, 229, 15, 15)
+    ca_dist = dist[:, :, :, ATOM.CA, ATOM.CA]
+    cb_dist = dist[:, :, :, ATOM.CB, ATOM.CB]
+    assert (ca_dist >= 0).all() and (cb_dist[~torch.isnan(cb_dist)] >= 0).all()
+    assert (ca_dist == dist[:, :, :, 1, 1]).all()
+
+
+def test_StructureBatch_backbone_orientations(ps):                      # :140
+    assert ps[0].from_pdb(ONE).backbone_orientations("N", "CA", "C").shape == (1, 229, 3, 3)
+
+
+def test_StructureBatch_backbone_translations(ps):                      # :148
+    sb = ps[0].from_pdb(ONE)
+    for atom in ["N", "CA", "C"]:
+        assert sb.backbone_translations(atom).shape == (1, 229, 3)
+
+
+def test_StructureBatch_get_chain_lengths(ps):                          # :157
+    lengths = ps[0].from_pdb(TWO).get_total_lengths()
+    assert (lengths.cpu() == torch.tensor([229, 434])).all()
+
+
+def test_StructureBatch_pairwise_dihedrals(ps):                         # :166
+    sb = ps[0].from_pdb([ONE])
+    assert sb.pairwise_dihedrals(atoms_i=["C"], atoms_j=["N", "CA", "C"]).shape == (1, 229, 229)     # phi(i, j)
+    assert sb.pairwise_dihedrals(atoms_i=["N", "CA", "C"], atoms_j=["N"]).shape == (1, 229, 229)     # psi(i, j)
+
+
+def test_get_local_xyz(ps):                                             # :179
+    sb = ps[0].from_pdb(TWO)
+    assert sb.get_local_xyz().shape == (2, 434, sb.get_max_n_atoms_per_residue(), 3)
+
+
+def test_from_backbone_orientations_translations(ps):                   # :189
+    SB = ps[0]
+    sb = SB.from_pdb([ONE])
+    args = (sb.backbone_orientations(), sb.backbone_translations(), sb.get_chain_idx(), sb.get_chain_ids(), sb.get_seq())
+    assert SB.from_backbone_orientations_translations(*args).get_max_n_atoms_per_residue() == 15
+    assert SB.from_backbone_orientations_translations(*args, include_cb=True).get_max_n_atoms_per_residue() == 15
+
+
+def test_standardize_unstandardize(ps):                                 # :210
+    sb = ps[0].from_pdb([ONE])
+    sb.standardize()
+    sb.unstandardize()
+
+
+def test_standardized_not_nan(ps):                                      # :218
+    sb = ps[0].from_pdb([ONE])
+    atom_mask = sb.get_atom_mask()
+    sb.standardize()
+    assert not torch.isnan(sb.get_xyz()[atom_mask.bool()]).any()
+
+
+def test_cannot_standardize_twice(ps):                                  # :229
+    sb = ps[0].from_pdb([ONE])
+    with pytest.raises(ValueError):
+        sb.standardize()
+        sb.standardize()
+
+
+def test_cannot_unstandardize_first(ps):                                # :238
+    with pytest.raises(ValueError):
+        ps[0].from_pdb([ONE]).unstandardize()
+
+
+def test_standardize_and_unstandardize_reverts_original_xyz_correctly(ps):   # :246
+    sb = ps[0].from_pdb([ONE])
+    xyz = sb.get_xyz().clone()        # (the build standardizes in place, SURVEY Q8: keep a copy of the original)
+    sb.standardize()
+    sb.unstandardize()
+    assert torch.allclose(xyz, sb.get_xyz(), equal_nan=True, rtol=1e-4, atol=1e-5)
+
+
+def test_center_at_origin(ps):                                          # :258
+    sb = ps[0].from_pdb([ONE])
+    sb.center_at()
+    com = sb.center_of_mass()
+    assert torch.allclose(com, torch.zeros_like(com), rtol=1e-4, atol=1e-5)
+
+
+def test_center_at_desired_points(ps):                                  # :268
+    sb = ps[0].from_pdb(TWO)
+    centers = torch.randn([2, 3])
+    sb.center_at(centers)
+    assert torch.allclose(sb.center_of_mass().cpu(), centers, rtol=1e-4, atol=1e-5)
+
+
+def test_get_residue_mask(ps):                                          # :278
+    assert ps[0].from_pdb(TWO).get_residue_mask().shape == (2, 434)
+
+
+def test_seq_idx(ps):                                                   # :286
+    sb = ps[0].from_pdb(TWO)
+    seq_idx, residue_mask = sb.get_seq_idx(), sb.get_residue_mask()
+    assert seq_idx.shape == (2, 434)
+    assert (seq_idx[~residue_mask.bool()] == 20).all()                  # AA.UNK
+
+
+def test_residue_masked_select(ps):                                     # :298
+    sb = ps[0].from_pdb([ONE])
+    mine = torch.randint(0, 2, size=sb.get_residue_mask().shape).bool()
+    assert sb.residue_masked_select(mine).get_xyz().shape == (1, mine.sum().item(), 15, 3)
+
+
+# ---------------------------------------------------------------- tests/test_geometry.py
+def test_dot_tensor(ps):                                                # :10
+    assert ps[1].dot(torch.tensor([1, 2, 3]), torch.tensor([4, 5, 6])) == 32
+
+
+def test_dot_numpy(ps):                                                 # :16
+    assert ps[1].dot(np.array([1, 2, 3]), np.array([4, 5, 6])) == 32
+
+
+def test_norm_tensor(ps):                                               # :22
+    a = torch.tensor([[1, 2, 3], [4, 5, 6]]).float()
+    n = ps[1].norm(a)
+    assert n.shape == (2, 1) and torch.isclose(n.cpu(), torch.tensor([[14 ** 0.5], [77 ** 0.5]])).all()
+
+
+def test_norm_numpy(ps):                                                # :28
+    a = np.array([[1, 2, 3], [4, 5, 6]]).astype(np.float32)
+    n = ps[1].norm(a)
+    assert isinstance(n, np.ndarray) and n.shape == (2, 1) and np.allclose(n, np.array([[14 ** 0.5], [77 ** 0.5]]))
+
+
+def _angle_points(as_numpy):
+    a = [[1, 0, 0], [1, 0, 0]]
+    b = [[0, 0, 0], [0, 0, 0]]
+    c = [[0, 1, 0], [0.5, math.sqrt(3) / 2, 0]]
+    conv = (lambda v: np.array(v, dtype=np.float32)) if as_numpy else (lambda v: torch.tensor(v).float())
+    return conv(a), conv(b), conv(c)
+
+
+def test_angle_tensor(ps):                                              # :35
+    angle = ps[1].angle(*_angle_points(False), to_degree=True).flatten()
+    assert isinstance(angle, torch.Tensor) and angle.shape == (2,)
+    assert torch.isclose(angle.cpu(), torch.tensor([90.0, 60.0])).all()
+
+
+def test_angle_numpy(ps):                                               # :62
+    angle = ps[1].angle(*_angle_points(True), to_degree=True).flatten()
+    assert isinstance(angle, np.ndarray) and angle.shape == (2,) and np.allclose(angle, [90.0, 60.0])
+
+
+def _dihedral_points(as_numpy):
+    # the reference's four points: (1,0,0), origin, (0,1,0), (0,1,1) -> -90 degrees under its sign convention
+    pts = ([[1, 0, 0]], [[0, 0, 0]], [[0, 1, 0]], [[0, 1, 1]])
+    conv = (lambda v: np.array(v, dtype=np.float32)) if as_numpy else (lambda v: torch.tensor(v).float())
+    return tuple(conv(p) for p in pts)
+
+
+def test_dihedral_tensor(ps):                                           # :92
+    d = ps[1].dihedral(*_dihedral_points(False), to_degree=True)
+    assert isinstance(d, torch.Tensor) and d.shape == (1,)
+    assert torch.isclose(d.cpu(), torch.tensor([-90.0])).all()
+
+
+def test_dihedral_numpy(ps):                                            # :121
+    d = ps[1].dihedral(*_dihedral_points(True), to_degree=True)
+    assert isinstance(d, np.ndarray) and d.shape == (1,) and np.allclose(d, [-90.0])
+
+
+def test_dihedral_for_higher_dimension(ps):                             # :154
+    a, b, c, d = (torch.randn(4, 7, 5, 3) for _ in range(4))
+    out = ps[1].dihedral(a, b, c, d)
+    assert out.shape == (4, 7, 5) and ((out >= -math.pi) & (out <= math.pi)).all()
+
+
+def test_gram_schmidt(ps):                                              # :235
+    a, b, c = (torch.randn(16, 30, 3) for _ in range(3))
+    assert ps[1].gram_schmidt(a, b, c).shape == (16, 30, 3, 3)
+
+
+def test_ideal_backbone_coordinates(ps):                                # :246
+    geom = ps[1]
+    xyz = geom.ideal_backbone_coordinates(size=(16, 30))
+    assert xyz.shape == (16, 30, 3, 3)
+    assert geom.ideal_backbone_coordinates(size=(16, 30), include_cb=True).shape == (16, 30, 4, 3)
+    frame = geom.gram_schmidt(xyz[:, :, 0], xyz[:, :, 1], xyz[:, :, 2])
+    assert frame.shape == (16, 30, 3, 3)
+    assert (frame.cpu() == torch.eye(3).expand(16, 30, -1, -1)).all()   # ideal coordinates give the identity frame, exactly
+
+
+def test_kabsch(ps):                                                    # :265
+    rotations, translations = ps[1].kabsch(torch.randn(100, 3), torch.randn(100, 3))
+    assert rotations.shape == (3, 3) and translations.shape == (3,)
