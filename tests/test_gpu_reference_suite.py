@@ -264,3 +264,19 @@ def test_ideal_backbone_coordinates(ps):                                # :246
 def test_kabsch(ps):                                                    # :265
     rotations, translations = ps[1].kabsch(torch.randn(100, 3), torch.randn(100, 3))
     assert rotations.shape == (3, 3) and translations.shape == (3,)
+
+
+# ---------------------------------------------------------------- tests/test_decorator.py (numpy <-> tensor polymorphism)
+def test_with_tensor(ps):                                               # :12
+    x = ps[1].dot(torch.tensor([1.0, 2.0, 3.0]), torch.tensor([4.0, 5.0, 6.0]))
+    assert isinstance(x, torch.Tensor) and float(x) == 32.0
+
+
+def test_with_numpy(ps):                                                # :22
+    x = ps[1].dot(np.array([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0]))
+    assert isinstance(x, np.ndarray) and float(np.asarray(x).reshape(-1)[0]) == 32.0
+
+
+def test_mixed(ps):                                                     # :32  (any tensor among the inputs -> tensor out)
+    x = ps[1].dot(torch.tensor([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0]))
+    assert isinstance(x, torch.Tensor) and float(x) == 32.0
