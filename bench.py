@@ -324,6 +324,10 @@ def main():
     elapsed = time.perf_counter() - t0
 
     kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    per_rank_kernel_ms = [kernel_ms]
+    if dist:   # every rank's own figure: the spread between ranks is the fast / slow output-buffer lottery
+        per_rank_kernel_ms = [None] * world
+        dist.all_gather_object(per_rank_kernel_ms, kernel_ms)
     elapsed, kernel_ms_max = max_over_ranks([elapsed, kernel_ms])
 
     # ---- verification of the timed buffers (outside the timed region) ----
@@ -375,6 +379,11 @@ def main():
     if dist:
         result["rccl_ranks"] = world if args.backend == "nccl" else 0
         result["dist_backend"] = args.backend
+        # value / roofline use the SLOWEST rank (max over ranks); the per-rank list shows how much of any shortfall
+        # against N = 1 is the per-allocation store rate of each rank's output buffers rather than the scaling
+        result["per_rank_kernel_ms"] = per_rank_kernel_ms
+        result["per_rank_frac_of_hbm_peak"] = [B * N_RES * N_RES * BYTES_PER_PAIR / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+                                               for ms in per_rank_kernel_ms]
 
     printed = threading.Event()
 
