@@ -982,7 +982,7 @@ struct FlatS {
     static constexpr int RPP = 256 / LPR;
     static constexpr int RS = A;                                          // float4 slots per staged residue
     static constexpr int G = 256 / AA;                                    // groups per pass
-    static constexpr int FL_LOG2 = A <= 5 ? 8 : 7;   // A = 5 with 128-pair chunks: 3.19 instead of 3.86 TB/s (profiles/r02_k1_a_sweep_*)
+    static constexpr int FL_LOG2 = A <= 3 ? 9 : (A <= 5 ? 8 : 7);   // A/B-tested: A = 5 with 128 pairs 3.19 instead of 3.86 TB/s, A = 4 with 512 4.79 instead of 5.07, A = 3 with 512 2.76 instead of 2.33
     static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
     static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
     static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;
@@ -1097,10 +1097,11 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatS(const float* __restr
             if (cl == 0) (is_row ? smi : smj)[p] = (uint32_t)(bal >> (LPR * (pl % FIELDS))) & abits;
         }
         __syncthreads();
-        if (dmask && tid < FLn) {
-            const unsigned rl = udiv_rcp((unsigned)(j_start + tid), (unsigned)N, rcpN);
-            smr[tid] = (tid >= lo && tid < hi) ? smi[rl] : 0u;
-        }
+        if (dmask)
+            for (int t = tid; t < FLn; t += 256) {   // (a loop: the chunk may be longer than the workgroup)
+                const unsigned rl = udiv_rcp((unsigned)(j_start + t), (unsigned)N, rcpN);
+                smr[t] = (t >= lo && t < hi) ? smi[rl] : 0u;
+            }
         __syncthreads();
         if (tid >= GP * AA) continue;   // idle in the sweeps; rejoins at the next chunk's barrier
         const int gq = tid / AA;        // this lane's group inside a pass
@@ -1118,7 +1119,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatS(const float* __restr
             }
             int rl = 0, nb = N - j_start, rl_loaded = -1;
             float4 pi[4];
-#pragma unroll 2
+#pragma unroll 1   // A/B against unroll 2 / 4 (tools/k1_ab_libs.py): equal for A = 4, 5; +3 % / +5 % for A = 8 / 3
             for (int pass = 0; pass < G_::NPD; ++pass) {
                 const int g = pass * GP + gq;
                 const int p = 4 * g;
