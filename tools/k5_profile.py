@@ -22,3 +22,10 @@ for _ in range(20):
 for _ in range(20):
     sb.backbone_dihedrals()
 torch.cuda.synchronize()
+# the whole loop in one launch (T = 300), with and without the per-step coordinates
+betas = torch.full((300, B), 0.01, device="cuda")
+for _ in range(5):
+    sb.diffuse_trajectory(betas)
+for _ in range(3):
+    sb.diffuse_trajectory(betas, want_xyz=True)
+torch.cuda.synchronize()
