@@ -1656,7 +1656,6 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
     if (!xyz || (!dist && !dist_mask) || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
-    if (B > 65535) return (int)hipErrorInvalidValue;
     K1Cfg g;
     ps_k1_config_default(&g);
     if (cfg) {
@@ -1702,6 +1701,8 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
     }
+    // the flat kernels above run on 1-D grids and take any batch size; the kernels below put the structure on grid.z
+    if (B > 65535) return (int)hipErrorInvalidValue;
     if (A == A15) {
         if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
         const int jt = g.jt ? g.jt : (N >= 256 ? 128 : 64);

@@ -1503,6 +1503,30 @@ def test_empty_batches(SB, B, N):
     assert sb.get_xyz().shape == (B, N, A, 3)
 
 
+def test_very_large_batch_of_short_structures(SB):
+    """70 000 peptides of 17 residues: the flat K1 kernels run on 1-D grids and take any batch size (pairs per launch
+    < 2^32); the kernels that put the structure on a grid axis refuse more than 65 535 structures with a clear
+    ValueError before anything is launched."""
+    B, N, A = 70000, 17, 15
+    g = torch.Generator().manual_seed(8)
+    xyz = torch.randn(B, N, A, 3, generator=g)
+    mask = torch.rand(B, N, A, generator=g) < 0.9
+    sb = SB.from_xyz(xyz, mask)
+    d, m = sb.pairwise_distance_matrix()
+    assert d.shape == (B, N, N, A, A)
+    for b in (0, 65535, 65536, B - 1):
+        rd, rm = O.pairwise_distance_matrix(xyz[b:b + 1], mask[b:b + 1])
+        assert_close(d[b:b + 1], rd)
+        assert torch.equal(m[b:b + 1].cpu(), rm)
+    assert int(m.view(torch.uint8).max()) <= 1 and not torch.isnan(d).any()
+    del d, m
+    with pytest.raises(ValueError, match="65535"):
+        sb.backbone_dihedrals()
+    with pytest.raises(ValueError, match="65535"):
+        sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"])
+    assert sb.backbone_orientations().shape == (B, N, 3, 3)        # per-residue kernels have no such limit
+
+
 def test_cpu_batch_raises_instead_of_falling_back(SB):
     xyz, mask = synth(1, 1, 4)
     sb = SB.from_xyz(xyz, mask, device="cpu")
