@@ -19,9 +19,11 @@ __global__ __launch_bounds__(256) void k2_backbone_dihedrals(const float* __rest
                                                              float* __restrict__ dihedrals,
                                                              uint8_t* __restrict__ dihedral_mask,
                                                              uint8_t* __restrict__ nterm_out,
-                                                             uint8_t* __restrict__ cterm_out, int N, int A) {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                             uint8_t* __restrict__ cterm_out, int N, int A,
+                                                             int n_tiles) {
+    // 1-D grid (residue tile fastest, then structure): any batch size
+    const int b = (int)(blockIdx.x / (unsigned)n_tiles);
+    const int i = (int)(blockIdx.x % (unsigned)n_tiles) * 256 + threadIdx.x;
     const int lane = threadIdx.x & (PS_WAVE - 1);
     const bool live = i < N;
     const int ic = live ? i : N - 1;  // clamp so every lane of the wave can take part in the shuffles
@@ -79,9 +81,11 @@ __global__ __launch_bounds__(256) void k2_backbone_dihedrals(const float* __rest
 extern "C" int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_idx, const uint8_t* residue_mask,
                                          float* dihedrals, uint8_t* dihedral_mask, uint8_t* nterm, uint8_t* cterm,
                                          int B, int N, int A, void* stream) {
-    if (!xyz || !chain_idx || !residue_mask || B < 0 || N < 0 || A < 3 || B > 65535) return (int)hipErrorInvalidValue;
+    if (!xyz || !chain_idx || !residue_mask || B < 0 || N < 0 || A < 3) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    return ps_launch(k2_backbone_dihedrals, dim3((N + 255) / 256, B), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), xyz, chain_idx, residue_mask, dihedrals, dihedral_mask,
-                       nterm, cterm, N, A);
+    const int n_tiles = (N + 255) / 256;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    return ps_launch(k2_backbone_dihedrals, dim3((unsigned)n_wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     xyz, chain_idx, residue_mask, dihedrals, dihedral_mask, nterm, cterm, N, A, n_tiles);
 }

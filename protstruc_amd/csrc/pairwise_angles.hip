@@ -25,10 +25,14 @@ struct AtomSel {
 template <int NP, int SRC>
 __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restrict__ xyz, float* __restrict__ out,
                                                           int N, int A, AtomSel sel, int row_begin, int row_end,
-                                                          int out_rows, int out_row_origin, int IR) {
-    const int b = blockIdx.z;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = row_begin + blockIdx.y * IR;
+                                                          int out_rows, int out_row_origin, int IR, int n_tiles,
+                                                          int n_chunks) {
+    // 1-D grid (column tile fastest, then row chunk, then structure): no 65 535 limit on any axis
+    const unsigned w = blockIdx.x;
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_chunks);
+    const int j = (int)tile * 256 + threadIdx.x;
+    const int i0 = row_begin + (int)(rest % (unsigned)n_chunks) * IR;
     const int i1 = min(i0 + IR, row_end);
     const bool live = j < N;
     const int jc = live ? j : N - 1;
@@ -80,10 +84,12 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int IR) {
-    const int b = blockIdx.z;
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int i0 = blockIdx.y * IR, i1 = min(i0 + IR, N);
+    int A, int IR, int n_tiles, int n_chunks) {
+    const unsigned w = blockIdx.x;   // 1-D grid as in k3_pairwise_angles
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_chunks);
+    const int j = (int)tile * 256 + threadIdx.x;
+    const int i0 = (int)(rest % (unsigned)n_chunks) * IR, i1 = min(i0 + IR, N);
     const bool live = j < N;
     const int jc = live ? j : N - 1;
     const float* sj = xyz + ((size_t)b * N + jc) * (size_t)A * 3;
@@ -152,9 +158,11 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
            int out_rows, int out_row_origin, hipStream_t s) {
     const int IR = 16;
     const int rows = row_end - row_begin;
-    dim3 grid((N + 255) / 256, (rows + IR - 1) / IR, B);
-    return ps_launch(k3_pairwise_angles<NP, SRC>, grid, dim3(256), 0, s, xyz, out, N, A, sel, row_begin, row_end,
-                       out_rows, out_row_origin, IR);
+    const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    return ps_launch(k3_pairwise_angles<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel, row_begin,
+                     row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
 }
 
 template <int NP, int... SRCS>
@@ -173,7 +181,7 @@ int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, con
 extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N, int A, int n_points, const int* src,
                                       const int* atom, int row_begin, int row_end, int out_rows, int out_row_origin,
                                       void* stream) {
-    if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0 || B > 65535) return (int)hipErrorInvalidValue;
+    if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
@@ -185,7 +193,6 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
         srcmask |= src[k] << k;
     }
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
-    if ((row_end - row_begin + 15) / 16 > 65535) return (int)hipErrorInvalidValue;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n_points == 4)
         return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(
@@ -200,11 +207,13 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                                              void* stream) {
     if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
         return (int)hipErrorInvalidValue;
-    if (B < 0 || N < 0 || A < 5 || B > 65535) return (int)hipErrorInvalidValue;
+    if (B < 0 || N < 0 || A < 5) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
     const int IR = 16;
-    if ((N + IR - 1) / IR > 65535) return (int)hipErrorInvalidValue;
-    return ps_launch(k3_inter_residue_geometry, dim3((N + 255) / 256, (N + IR - 1) / IR, B), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
-                       d_ca_mask, d_cb_mask, d_no_mask, N, A, IR);
+    const int n_tiles = (N + 255) / 256, n_chunks = (N + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    return ps_launch(k3_inter_residue_geometry, dim3((unsigned)n_wg), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
+                     d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
 }

@@ -74,14 +74,6 @@ def _check_out(t: Optional[torch.Tensor], shape, name: str, device: torch.device
         raise ValueError(f"{name} must be a contiguous float32 tensor of shape {tuple(shape)} on {device}")
 
 
-_MAX_GRID_BATCH = 65535   # kernels that put the structure on grid.y / grid.z (see include/protstruc_hip.h)
-
-
-def _check_batch(B: int, what: str) -> None:
-    if B > _MAX_GRID_BATCH:
-        raise ValueError(f"{what}: batch size {B} exceeds {_MAX_GRID_BATCH} structures per launch; split the batch")
-
-
 def _ptr(t: Optional[torch.Tensor]):
     # a plain int is what ctypes wants for a c_void_p argument (None = NULL); no wrapper object per pointer
     return None if t is None else t.data_ptr()
@@ -328,7 +320,6 @@ def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask:
     chain = _f32c(chain_idx, "chain_idx")
     rmask = _u8c(residue_mask, "residue_mask")
     dev = xyz.device
-    _check_batch(B, "backbone_dihedrals")
     if not (want_dihedrals or want_mask or want_nterm or want_cterm):
         raise ValueError("at least one output must be requested")
     with _on(dev):
@@ -356,7 +347,6 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
     B, N, A = xyz.shape[:3]
     slots = [int(s) for s in slots_i] + [int(s) for s in slots_j]
     src = [0] * len(slots_i) + [1] * len(slots_j)
-    _check_batch(B, "pairwise_angles")
     if len(slots) < n_points:
         raise IndexError(f"need {n_points} atoms in total, got {len(slots)}")  # the reference indexes past the end
     slots, src = slots[:n_points], src[:n_points]
@@ -385,7 +375,7 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
     B, N, A = xyz.shape[:3]
     if A < 5:
         raise IndexError("inter_residue_geometry needs the N, CA, C, O, CB atom slots")
-    _check_batch(B, "inter_residue_geometry")
+
     m = _u8c(atom_mask, "atom_mask")
     dev = xyz.device
     fkeys = ["d_ca", "d_cb", "d_no", "omega", "theta", "phi"]

@@ -1505,8 +1505,7 @@ def test_empty_batches(SB, B, N):
 
 def test_very_large_batch_of_short_structures(SB):
     """70 000 peptides of 17 residues: the flat K1 kernels run on 1-D grids and take any batch size (pairs per launch
-    < 2^32); the kernels that put the structure on a grid axis refuse more than 65 535 structures with a clear
-    ValueError before anything is launched."""
+    < 2^32), and so do K2 / K3 / K4."""
     B, N, A = 70000, 17, 15
     g = torch.Generator().manual_seed(8)
     xyz = torch.randn(B, N, A, 3, generator=g)
@@ -1520,11 +1519,18 @@ def test_very_large_batch_of_short_structures(SB):
         assert torch.equal(m[b:b + 1].cpu(), rm)
     assert int(m.view(torch.uint8).max()) <= 1 and not torch.isnan(d).any()
     del d, m
-    with pytest.raises(ValueError, match="65535"):
-        sb.backbone_dihedrals()
-    with pytest.raises(ValueError, match="65535"):
-        sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"])
-    assert sb.backbone_orientations().shape == (B, N, 3, 3)        # per-residue kernels have no such limit
+    # K2 / K3 / K4 run on 1-D grids: no batch limit either
+    chain = torch.zeros(B, N)
+    dih, dmask = sb.backbone_dihedrals()
+    om = sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"])
+    ph = sb.pairwise_planar_angles(["CA", "CB"], ["CB"])
+    for b in (0, 65535, 65536, B - 1):
+        rdih, rdm = O.backbone_dihedrals(xyz[b:b + 1], chain[b:b + 1], mask[b:b + 1].any(-1))
+        assert_close(dih[b:b + 1], rdih, bad_frac=0.02)
+        assert torch.equal(dmask[b:b + 1].cpu(), rdm)
+        assert_close(om[b:b + 1], O.pairwise_dihedrals(xyz[b:b + 1], [1, 4], [1, 4]), bad_frac=0.01)
+        assert_close(ph[b:b + 1], O.pairwise_planar_angles(xyz[b:b + 1], [1, 4], [4]), bad_frac=0.01)
+    assert sb.backbone_orientations().shape == (B, N, 3, 3)
 
 
 def test_cpu_batch_raises_instead_of_falling_back(SB):
