@@ -94,8 +94,9 @@ void ps_k1_config_default(ps_k1_config* cfg);
  * `atom_mask` may be NULL (all atoms present); `dist_mask` may be NULL (mask
  * plane not produced); `dist` may be NULL (only the mask plane produced).
  * Limits (hipErrorInvalidValue beyond them): B * out_rows * N < 2^32 pairs per launch for the flat kernels
- * (any N >= 16 that is not a multiple of 16, and every fixed-A atom count); B <= 65535 for the kernels that put the
- * structure on grid.z (A = 15 with N % 16 == 0 or N < 16, and the element-per-lane kernel).  K2 / K3 run on 1-D
+ * (any N >= 16 that is not a multiple of 16, and every fixed-A atom count), 2^31 workgroups for the pattern kernel
+ * (A = 15, N % 16 == 0); B <= 65535 only for the two simple kernels that put the structure on grid.z (N < 16,
+ * unaligned planes, atom counts without a flat kernel).  K2 / K3 run on 1-D
  * grids: any batch size up to 2^31 workgroups per launch.
  * Arithmetic: sqrt((dx*dx + dy*dy) + dz*dz) in fp32 without contraction; the square
  * root is the hardware instruction (exact for 85 % of inputs, 1 ulp off otherwise)

@@ -1485,6 +1485,7 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
         return ex ? PS_K1_PAT(false, 1, false) : PS_K1_PAT(false, 0, false);
 #undef PS_K1_PAT
     }
+    if (B > 65535) return (int)hipErrorInvalidValue;   // slot-decode kernel: structure on grid.z
     if (da && ma) return g.store_nt ? PS_K1_LAUNCH(true, true, true) : PS_K1_LAUNCH(false, true, true);
     if (da) return PS_K1_LAUNCH(true, true, false);
     return PS_K1_LAUNCH(true, false, false);
@@ -1701,8 +1702,8 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
     }
-    // the flat kernels above run on 1-D grids and take any batch size; the kernels below put the structure on grid.z
-    if (B > 65535) return (int)hipErrorInvalidValue;
+    // the flat kernels above and the pattern kernel run on 1-D grids and take any batch size; the slot-decode and the
+    // element-per-lane kernels put the structure on grid.z (checked where they are launched)
     if (A == A15) {
         if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
         const int jt = g.jt ? g.jt : (N >= 256 ? 128 : 64);
@@ -1712,7 +1713,7 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         return launch_a15<64>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
                               s);
     }
-    if (rows > 65535) return (int)hipErrorInvalidValue;
+    if (rows > 65535 || B > 65535) return (int)hipErrorInvalidValue;   // element kernel: (row, structure) on grid.y / grid.z
     const unsigned long long nE = (unsigned long long)N * A * A;
     if (nE > 0xFFFFFFFFull) return (int)hipErrorInvalidValue;
     unsigned gx = (unsigned)((nE + 255) / 256);

@@ -1531,6 +1531,13 @@ def test_very_large_batch_of_short_structures(SB):
         assert_close(om[b:b + 1], O.pairwise_dihedrals(xyz[b:b + 1], [1, 4], [1, 4]), bad_frac=0.01)
         assert_close(ph[b:b + 1], O.pairwise_planar_angles(xyz[b:b + 1], [1, 4], [4]), bad_frac=0.01)
     assert sb.backbone_orientations().shape == (B, N, 3, 3)
+    # N = 16: the pattern kernel (N % 16 == 0), also on a 1-D grid
+    x16, m16 = xyz[:, :16].contiguous(), mask[:, :16].contiguous()
+    d16, k16 = SB.from_xyz(x16, m16).pairwise_distance_matrix()
+    for b in (0, 65535, 65536, B - 1):
+        rd, rm = O.pairwise_distance_matrix(x16[b:b + 1], m16[b:b + 1])
+        assert_close(d16[b:b + 1], rd)
+        assert torch.equal(k16[b:b + 1].cpu(), rm)
 
 
 def test_cpu_batch_raises_instead_of_falling_back(SB):
