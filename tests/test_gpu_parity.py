@@ -96,6 +96,39 @@ def test_k1_vs_oracle(SB, B, N):
     assert torch.equal(m.cpu(), rm)
 
 
+@pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12)])
+def test_k1_special_values(SB, A, N):
+    """Infinite, huge, tiny, NaN and signed-zero coordinates propagate exactly as in the reference's arithmetic
+    (protstruc.py:477-479: difference, square, sum, square root; nothing is masked or clamped): NaN and inf positions
+    equal the oracle's, finite values within 1e-5 relative, in every K1 kernel family and both square-root modes."""
+    from protstruc_amd import ops
+    g = torch.Generator().manual_seed(90 + A)
+    xyz = torch.randn(2, N, A, 3, generator=g)
+    xyz[0, 1, 0] = float("inf")
+    xyz[0, 2, 1, 0] = float("-inf")
+    xyz[0, 3, 2] = float("nan")
+    xyz[0, 4, 0] = 3e19            # squares overflow to inf
+    xyz[0, 5, 0] = torch.tensor([1e-25, -1e-25, 0.0])
+    xyz[0, 6, 0] = torch.tensor([-0.0, 0.0, -0.0])
+    xyz[1, 0, :] = xyz[1, 1, :]    # two identical residues: exact zeros off the diagonal
+    mask = torch.rand(2, N, A, generator=g) < 0.8
+    want, wmask = O.pairwise_distance_matrix(xyz, mask)
+    for exact in (False, True):
+        ops.set_exact_sqrt(exact)
+        try:
+            d, m = SB.from_xyz(xyz, mask).pairwise_distance_matrix()
+        finally:
+            ops.set_exact_sqrt(False)
+        d = d.cpu()
+        assert torch.equal(m.cpu(), wmask)
+        assert torch.equal(d.isnan(), want.isnan()), "NaN positions"
+        assert torch.equal(d.isinf(), want.isinf()), "inf positions"
+        fin = torch.isfinite(want)
+        rel = ((d[fin] - want[fin]).abs() / want[fin].clamp_min(1e-30))
+        assert (rel[want[fin] > 0] <= 1e-5).all()
+        assert (d[fin][want[fin] == 0] == 0).all(), "exact zeros stay exact zeros"
+
+
 def test_k1_no_mask_and_symmetry(SB):
     xyz, _ = synth(7, 2, 48)
     d, m = SB.from_xyz(xyz).pairwise_distance_matrix()
@@ -934,6 +967,32 @@ def test_config5_full_T300_graph(SB):
     mean = (z * w).sum((1, 2)) / cnt
     var = (((z - mean[:, None, None]) ** 2) * w).sum((1, 2)) / cnt
     assert mean.abs().max().item() < 0.08 and (var - 1).abs().max().item() < 0.12
+
+
+@pytest.mark.parametrize("N", [5, 64, 257, 300])
+def test_k3_row_ranges_compact_and_in_place(SB, N):
+    """K3's row_begin / row_end addressing (what the multi-GPU row sharding uses): compact and in-place results of
+    arbitrary row ranges equal the corresponding rows of the full result bit for bit, nothing outside the range is
+    written, for dihedrals and planar angles and several point splits."""
+    from protstruc_amd import ops
+    xyz, _ = synth(70 + N, 3, N)
+    xg = xyz.cuda()
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    rng = np.random.default_rng(N)
+    for npts, si, sj in [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (4, [2], [0, 1, 2]), (3, [1, 4], [4]), (3, [1], [1, 4])]:
+        full = ops.pairwise_angles(xg, si, sj, npts)
+        for _ in range(4):
+            r0 = int(rng.integers(0, N)); r1 = int(rng.integers(r0, N + 1))
+            c = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True)
+            assert c.shape == (3, r1 - r0, N) and same(c, full[:, r0:r1])
+            buf = torch.full((3, N, N), 321.0, device="cuda")
+            out = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
+            assert out is buf and same(buf[:, r0:r1], full[:, r0:r1])
+            assert (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+    with pytest.raises(ValueError):
+        ops.pairwise_angles(xg, [1, 4], [1, 4], 4, row_begin=3, row_end=2)
+    with pytest.raises(ValueError):
+        ops.pairwise_angles(xg, [1, 4], [1, 4], 4, out=torch.empty(3, N, N + 1, device="cuda"))
 
 
 def test_k3_errors(SB):
