@@ -1202,6 +1202,140 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatS(const float* __restr
     }
 }
 
+// ---- row-tile kernel for the small even atom counts whose pair block is a whole number of 16-byte slots (A = 4, 8) ----
+// With A*A a multiple of 16 every pair's distance block (A*A floats) and mask block (A*A bytes) starts 16-byte aligned
+// for ANY N, and a float4 slot never leaves one row atom a and one column residue j.  So the lane -> (j, a, c..c+3)
+// pattern can be laid over a ROW instead of over pair positions: a workgroup owns IR rows x JT column residues of one
+// structure, a lane owns the same slots of every row, and -- the point of this kernel -- its four COLUMN atoms stay in
+// registers for all IR rows: the inner loop is one LDS read (the row atom) + four distances + one 16-byte store,
+// against four LDS reads per slot and a per-chunk re-staging of every pair position in the flat kernels (whose
+// staging is O(A) per pair against O(A^2) output: for A = 4 that is 64 bytes of LDS image per 80 bytes of output).
+// A run of one row is JT*A*A*4 = 8 KB (mask: 2 KB); rows are N*A*A*4 bytes apart.  Row-sharded launches need nothing
+// special (rows are the outer axis, as in the A = 15 pattern kernel).
+template <int A>
+struct RowTile {
+    static_assert(A == 4 || A == 8, "row-tile kernel: A*A must be a multiple of 16 and a slot must stay inside one row atom");
+    static constexpr int AA = A * A;
+    static constexpr int JT = 2048 / AA;               // column residues per tile: 512 float4 slots = 8 KB per row
+    static constexpr int SPL = 2;                      // slots per lane per row
+    static constexpr int MS = JT * AA / 16;            // 16-byte mask slots per row = 128
+    static constexpr int RPS = 16 / A;                 // row atoms (a) per mask slot
+};
+
+template <int A, bool EXACT>
+__global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restrict__ xyz,
+                                                           const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                           int N, int row_begin, int row_end, int out_rows,
+                                                           int out_row_origin, int IR, int n_tiles, int n_ichunks,
+                                                           int xcd_remap) {
+    using T = RowTile<A>;
+    constexpr int AA = T::AA, JT = T::JT;
+    extern __shared__ __attribute__((aligned(16))) char smem_rt[];
+    float4* sxj = reinterpret_cast<float4*>(smem_rt);           // [JT * A]
+    float4* sxi = sxj + JT * A;                                  // [IR * A]
+    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A);  // [JT] column mask bits
+    uint32_t* smi = smj + JT;                                    // [IR] row mask bits
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) w = (w & 7u) * (gridDim.x >> 3) + (w >> 3);   // host guarantees gridDim.x % 8 == 0 when set
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_ichunks);
+    const int j0 = (int)tile * JT;
+    const int jn = min(JT, N - j0);
+    const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
+    const int in = min(IR, row_end - i0);
+
+    {   // stage: coalesced dword loads of the flat coordinate rows, one float4 slot per atom
+        const float* gj = xyz + ((size_t)b * N + j0) * (A * 3);
+        float* lj = reinterpret_cast<float*>(sxj);
+        for (int f = tid; f < jn * (A * 3); f += 256) {
+            const int atom = f / 3, comp = f - atom * 3;
+            lj[atom * 4 + comp] = gj[f];
+        }
+        const float* gi = xyz + ((size_t)b * N + i0) * (A * 3);
+        float* li = reinterpret_cast<float*>(sxi);
+        for (int f = tid; f < in * (A * 3); f += 256) {
+            const int atom = f / 3, comp = f - atom * 3;
+            li[atom * 4 + comp] = gi[f];
+        }
+        for (int r = tid; r < JT + IR; r += 256) {
+            const bool is_j = r < JT;
+            const int rl = is_j ? r : r - JT;
+            const bool valid = is_j ? (rl < jn) : (rl < in);
+            uint32_t bits = 0;
+            if (valid) {
+                if (amask) {
+                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A;
+#pragma unroll
+                    for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+                } else {
+                    bits = (1u << A) - 1u;
+                }
+            }
+            (is_j ? smj : smi)[rl] = bits;
+        }
+    }
+    __syncthreads();
+
+    const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;  // pair index of (i0, j0)
+    const size_t row_stride = (size_t)N * AA;
+
+    if (dist) {
+        // slot s = tid + 256 u of the row run: elements 4 s .. 4 s + 3 = (j, a, c0 .. c0 + 3), the same in every row
+        float4 q[T::SPL][4];
+        unsigned ai[T::SPL];
+        bool act[T::SPL];
+#pragma unroll
+        for (int u = 0; u < T::SPL; ++u) {
+            const unsigned e = 4u * ((unsigned)tid + 256u * u);
+            const unsigned j = e / AA, r = e - j * AA;
+            ai[u] = r / A;
+            const unsigned c0 = r - ai[u] * A;
+            act[u] = (int)j < jn;
+            const unsigned jj = act[u] ? j : 0u;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) q[u][kk] = sxj[jj * A + c0 + kk];   // the column atoms: registers for all rows
+        }
+        float* o = dist + row0 * AA + 4u * tid;
+#pragma unroll 2
+        for (int il = 0; il < in; ++il) {
+#pragma unroll
+            for (int u = 0; u < T::SPL; ++u) {
+                const float4 pi = sxi[il * A + ai[u]];
+                uint4 v;
+                v.x = __float_as_uint(dist_pp<EXACT>(pi, q[u][0]));
+                v.y = __float_as_uint(dist_pp<EXACT>(pi, q[u][1]));
+                v.z = __float_as_uint(dist_pp<EXACT>(pi, q[u][2]));
+                v.w = __float_as_uint(dist_pp<EXACT>(pi, q[u][3]));
+                if (act[u]) store16<false>(o + 1024 * u, v);
+            }
+            o += row_stride;
+        }
+    }
+
+    if (dmask) {
+        // 128 mask slots per row: lane t takes slot t % 128 of the rows with parity t / 128
+        const int ms = tid & (T::MS - 1), par = tid / T::MS;
+        const unsigned e0 = 16u * (unsigned)ms;
+        const unsigned j = e0 / AA, a0 = (e0 - j * AA) / A;   // the slot covers row atoms a0 .. a0 + RPS - 1 of pair j
+        if ((int)j < jn) {
+            const uint32_t mj = smj[j];
+            uint8_t* o = dmask + (row0 + (size_t)par * N) * AA + e0;
+            for (int il = par; il < in; il += 2) {
+                const uint32_t mi = smi[il] >> a0;
+                uint32_t win = 0;
+#pragma unroll
+                for (int t = 0; t < T::RPS; ++t) win |= ((mi >> t) & 1u) ? (mj << (A * t)) : 0u;
+                store16<false>(o, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                             spread4((win >> 12) & 15u)));
+                o += 2 * row_stride;
+            }
+        }
+    }
+}
+
 // ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
 // Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
 // fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
@@ -1531,6 +1665,31 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
 // from_xyz test, tests/test_StructureBatch.py:11-21) and 16;
 // A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
 // kernel (cfg.flat == 4).  Other atom counts take the any-A flat kernel.
+// Row-tile kernel (A = 4, 8): any N, any row range; planes must be 16-byte aligned.
+bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int A) {
+    if (g.variant != 0 || g.flat != 1) return false;   // flat = 3 / 4 force the flat kernels (cross-checks), 0 the simple one
+    if (A != 4 && A != 8) return false;
+    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
+template <int A>
+int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
+                   int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+    constexpr int JT = RowTile<A>::JT;
+    const int rows = row_end - row_begin;
+    const int IR = rows < 32 ? rows : 32;              // 32 rows x 8 KB + 2 KB of mask = 320 KB per workgroup at most
+    const int n_tiles = (N + JT - 1) / JT, n_ichunks = (rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
+    const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + IR) * sizeof(uint32_t);
+    if (g.exact_sqrt)
+        return ps_launch(k1_pairdist_rowtile<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask,
+                         N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+    return ps_launch(k1_pairdist_rowtile<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, N,
+                     row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+}
+
 bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
 
 bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
@@ -1666,6 +1825,11 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
+    if (rowtile_eligible(g, dist, dist_mask, A)) {
+        if (A == 4)
+            return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+        return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+    }
     if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
         const bool whole = rows == out_rows;

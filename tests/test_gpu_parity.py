@@ -96,7 +96,7 @@ def test_k1_vs_oracle(SB, B, N):
     assert torch.equal(m.cpu(), rm)
 
 
-@pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12)])
+@pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12), (4, 9), (4, 131), (8, 33), (8, 7)])
 def test_k1_special_values(SB, A, N):
     """Infinite, huge, tiny, NaN and signed-zero coordinates propagate exactly as in the reference's arithmetic
     (protstruc.py:477-479: difference, square, sum, square root; nothing is masked or clamped): NaN and inf positions
@@ -251,7 +251,8 @@ def _same_floats(a, b):
 
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
-    """The vectorised any-A flat kernel (k1_flat=3) and the fixed-A flat pattern kernel (k1_flat=4; A in 14, 15, 37)
+    """The vectorised any-A flat kernel (k1_flat=3), the fixed-A flat pattern kernels (k1_flat=4) and the row-tile
+    kernel of A = 4 / 8 (k1_flat=1, the default dispatch)
     against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
     at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
@@ -266,9 +267,12 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              (2, 16, 14), (3, 300, 14), (2, 129, 14), (1, 16, 37), (2, 17, 37), (2, 130, 37), (2, 200, 15), (3, 19, 15),
              (2, 90, 16), (2, 70, 25), (1, 16, 25),
              # small fixed-A kernel (several 4-pair groups per pass, per-lane row bookkeeping): N < pairs per pass
-             (3, 16, 3), (2, 100, 3), (4, 16, 4), (2, 17, 4), (3, 19, 5), (2, 300, 5), (2, 23, 8), (2, 200, 8)]
+             (3, 16, 3), (2, 100, 3), (4, 16, 4), (2, 17, 4), (3, 19, 5), (2, 300, 5), (2, 23, 8), (2, 200, 8),
+             # row-tile kernel (A = 4, 8; the default dispatch): partial tiles, more rows than one workgroup takes
+             (2, 129, 4), (1, 300, 4), (2, 33, 8), (1, 70, 8)]
     try:
-        for (B, N, A), flat in [(c, f) for c in cases for f in ((3, 4) if c[2] in (3, 4, 5, 8, 14, 15, 16, 25, 37) else (3,))]:
+        for (B, N, A), flat in [(c, f) for c in cases
+                             for f in ((1, 3, 4) if c[2] in (4, 8) else (3, 4) if c[2] in (3, 5, 14, 15, 16, 25, 37) else (3,))]:
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
