@@ -1336,6 +1336,157 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
     }
 }
 
+// ---- row-tile kernel for small ODD atom counts on aligned lengths (A = 3, 5 with N % 16 == 0) ----
+// The same column-stationary idea for pair blocks that are NOT a whole number of 16-byte slots: when N % 16 == 0 every
+// row run still starts 16-byte aligned in both planes, so slot s of a row tile decodes to the same four
+// (column residue, column atom) and the same four row atoms in every row.  The four column atoms stay in registers for
+// all rows; the (up to two distinct) row atoms of a slot are read per row.  A tile is JT column residues with JT a
+// multiple of 16 chosen so that a row run is just under 512 float4 slots (A = 5: 80 residues = 500 slots = 8 000 B;
+// A = 3: 224 residues = 504 slots).  A mask slot spans up to 2 + 14/A row atoms of up to three column residues, all of
+// the same row residue: the column masks stay in registers, the row's mask bits arrive once per row.
+// Lengths that are not a multiple of 16 keep the flat small-A kernel.
+template <int A>
+struct RowTileOdd {
+    static_assert(A == 3 || A == 5 || A == 7, "odd row-tile kernel");
+    static constexpr int AA = A * A;
+    static constexpr int JT = ((2048 / AA) / 16) * 16;   // column residues per tile: <= 512 dist slots, whole mask slots
+    static constexpr int DS = JT * AA / 4;               // float4 slots per row run (A = 5: 500, A = 3: 504)
+    static constexpr int SPL = (DS + 255) / 256;         // 2
+    static constexpr int MS = JT * AA / 16;              // 16-byte mask slots per row run (<= 128)
+    static constexpr int MR = 2 + 14 / A;                // row atoms a mask slot can span
+    static constexpr int MP = (16 + AA - 2) / AA + 1;    // column residues a mask slot can touch (A = 3: 3, A = 5: 2)
+};
+
+template <int A, bool EXACT>
+__global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __restrict__ xyz,
+                                                               const uint8_t* __restrict__ amask,
+                                                               float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                               int N, int row_begin, int row_end, int out_rows,
+                                                               int out_row_origin, int IR, int n_tiles, int n_ichunks,
+                                                               int xcd_remap) {
+    using T = RowTileOdd<A>;
+    constexpr int AA = T::AA, JT = T::JT;
+    extern __shared__ __attribute__((aligned(16))) char smem_ro[];
+    float4* sxj = reinterpret_cast<float4*>(smem_ro);           // [JT * A]
+    float4* sxi = sxj + JT * A;                                  // [IR * A]
+    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A);  // [JT + 2] column mask bits (two zero guards)
+    uint32_t* smi = smj + (JT + 2);                              // [IR]
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) w = (w & 7u) * (gridDim.x >> 3) + (w >> 3);
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_ichunks);
+    const int j0 = (int)tile * JT;
+    const int jn = min(JT, N - j0);   // a multiple of 16 (N % 16 == 0, JT % 16 == 0)
+    const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
+    const int in = min(IR, row_end - i0);
+
+    {
+        const float* gj = xyz + ((size_t)b * N + j0) * (A * 3);
+        float* lj = reinterpret_cast<float*>(sxj);
+        for (int f = tid; f < jn * (A * 3); f += 256) {
+            const int atom = f / 3, comp = f - atom * 3;
+            lj[atom * 4 + comp] = gj[f];
+        }
+        const float* gi = xyz + ((size_t)b * N + i0) * (A * 3);
+        float* li = reinterpret_cast<float*>(sxi);
+        for (int f = tid; f < in * (A * 3); f += 256) {
+            const int atom = f / 3, comp = f - atom * 3;
+            li[atom * 4 + comp] = gi[f];
+        }
+        for (int r = tid; r < JT + 2 + IR; r += 256) {
+            const bool is_j = r < JT + 2;
+            const int rl = is_j ? r : r - (JT + 2);
+            const bool valid = is_j ? (rl < jn) : (rl < in);
+            uint32_t bits = 0;
+            if (valid) {
+                if (amask) {
+                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A;
+#pragma unroll
+                    for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+                } else {
+                    bits = (1u << A) - 1u;
+                }
+            }
+            (is_j ? smj : smi)[rl] = bits;
+        }
+    }
+    __syncthreads();
+
+    const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;
+    const size_t row_stride = (size_t)N * AA;
+    const int nslots = jn * AA / 4;    // whole slots: jn % 16 == 0
+
+    if (dist) {
+        float4 q[T::SPL][4];
+        unsigned ai[T::SPL][4];
+        bool act[T::SPL];
+#pragma unroll
+        for (int u = 0; u < T::SPL; ++u) {
+            const unsigned sl = (unsigned)tid + 256u * u;
+            act[u] = (int)sl < nslots;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const unsigned e = act[u] ? 4u * sl + kk : 0u;
+                const unsigned j = e / AA, r = e - j * AA;
+                ai[u][kk] = r / A;
+                q[u][kk] = sxj[j * A + (r - ai[u][kk] * A)];   // column atom of this element: registers for all rows
+            }
+        }
+        float* o = dist + row0 * AA + 4u * tid;
+        for (int il = 0; il < in; ++il) {
+#pragma unroll
+            for (int u = 0; u < T::SPL; ++u) {
+                const float4* xi = sxi + il * A;
+                uint4 v;
+                v.x = __float_as_uint(dist_pp<EXACT>(xi[ai[u][0]], q[u][0]));
+                v.y = __float_as_uint(dist_pp<EXACT>(xi[ai[u][1]], q[u][1]));
+                v.z = __float_as_uint(dist_pp<EXACT>(xi[ai[u][2]], q[u][2]));
+                v.w = __float_as_uint(dist_pp<EXACT>(xi[ai[u][3]], q[u][3]));
+                if (act[u]) store16<false>(o + 1024 * u, v);
+            }
+            o += row_stride;
+        }
+    }
+
+    if (dmask) {
+        // MS (<= 128) mask slots per row: lane t takes slot t % 128 of the rows with parity t / 128
+        const int ms = tid & 127, par = tid >> 7;
+        if (ms < jn * AA / 16) {
+            const unsigned e0 = 16u * (unsigned)ms;
+            const unsigned j = e0 / AA, r = e0 - j * AA;
+            const unsigned a = r / A, c = r - a * A;
+            uint32_t mjr[T::MR];      // column mask of the pair each spanned row atom belongs to
+            unsigned arow[T::MR];
+            int sh[T::MR];
+#pragma unroll
+            for (int m = 0; m < T::MR; ++m) {
+                const unsigned am = a + m, dp = am / A;
+                arow[m] = am - dp * A;
+                sh[m] = m * A - (int)c;
+                mjr[m] = smj[min(j + dp, (unsigned)(JT + 1))];   // guards hold 0; rows with sh >= 16 are not used
+            }
+            uint8_t* o = dmask + (row0 + (size_t)par * N) * AA + e0;
+            for (int il = par; il < in; il += 2) {
+                const uint32_t mi = smi[il];
+                uint32_t win = 0;
+#pragma unroll
+                for (int m = 0; m < T::MR; ++m) {
+                    if (sh[m] < 16) {
+                        const uint32_t bits = ((mi >> arow[m]) & 1u) ? mjr[m] : 0u;
+                        win |= sh[m] <= 0 ? (bits >> (-sh[m])) : (bits << sh[m]);
+                    }
+                }
+                win &= 0xFFFFu;
+                store16<false>(o, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                             spread4((win >> 12) & 15u)));
+                o += 2 * row_stride;
+            }
+        }
+    }
+}
+
 // ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
 // Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
 // fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
@@ -1672,6 +1823,31 @@ bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, i
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
+// Odd small atom counts: only lengths with N % 16 == 0 (every row run 16-byte aligned in both planes).
+bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
+    if (g.variant != 0 || g.flat != 1) return false;
+    if ((A != 3 && A != 5) || N % 16 != 0) return false;
+    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
+template <int A>
+int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
+                       int N, int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+    constexpr int JT = RowTileOdd<A>::JT;
+    const int rows = row_end - row_begin;
+    const int IR = rows < 32 ? rows : 32;
+    const int n_tiles = (N + JT - 1) / JT, n_ichunks = (rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
+    const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + 2 + IR) * sizeof(uint32_t);
+    if (g.exact_sqrt)
+        return ps_launch(k1_pairdist_rowtile_odd<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist,
+                         dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+    return ps_launch(k1_pairdist_rowtile_odd<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask,
+                     N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+}
+
 template <int A>
 int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                    int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
@@ -1829,6 +2005,11 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         if (A == 4)
             return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
         return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+    }
+    if (rowtile_odd_eligible(g, dist, dist_mask, N, A)) {
+        if (A == 3)
+            return launch_rowtile_odd<3>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+        return launch_rowtile_odd<5>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
     }
     if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
