@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
     const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
     const int b = (int)(rest / (unsigned)n_ichunks);
     const int j0 = (int)tile * JT;
-    const int jn = min(JT, N - j0);   // a multiple of 16 (N % 16 == 0, JT % 16 == 0)
+    const int jn = min(JT, N - j0);   // a multiple of 4 (N % 4 == 0, JT % 16 == 0); of 16 whenever the mask is written here
     const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
     const int in = min(IR, row_end - i0);
 
@@ -1416,7 +1416,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
 
     const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;
     const size_t row_stride = (size_t)N * AA;
-    const int nslots = jn * AA / 4;    // whole slots: jn % 16 == 0
+    const int nslots = jn * AA / 4;    // whole slots: jn % 4 == 0
 
     if (dist) {
         float4 q[T::SPL][4];
@@ -1484,6 +1484,94 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
                 o += 2 * row_stride;
             }
         }
+    }
+}
+
+// ---- mask plane of whole row blocks, any alignment (small odd atom counts on lengths with N % 4 == 0) ----
+// When N % 4 == 0 but N % 16 != 0 the DISTANCE plane's row runs are still 16-byte aligned (the row-tile kernel above
+// takes them) but the mask plane's are not.  The mask needs no coordinates and no per-lane pattern worth keeping in
+// registers, so it gets the simplest possible form: a workgroup owns IR consecutive rows of one structure -- one
+// contiguous byte range of the mask plane -- cuts it into absolute 16-byte slots, decodes each slot's first byte to
+// (row, column residue, a, c) at run time and ORs together the (up to 2 + 14/A) mask rows the slot spans, which may
+// continue into the next column residue and, at the end of a row, into the next row.  The ragged head and tail of the
+// range (< 16 bytes each) are written byte-wise.
+template <int A>
+__global__ __launch_bounds__(256) void k1_mask_rows(const uint8_t* __restrict__ amask, uint8_t* __restrict__ dmask,
+                                                    int N, int row_begin, int row_end, int out_rows,
+                                                    int out_row_origin, int IR, int n_ichunks) {
+    constexpr int AA = A * A, MR = 2 + 14 / A;
+    extern __shared__ uint32_t smask[];       // [N] column residues' mask bits | [IR + 1] row residues' (one zero guard)
+    uint32_t* smj = smask;
+    uint32_t* smi = smask + N;
+    const int tid = threadIdx.x;
+    const int b = (int)(blockIdx.x / (unsigned)n_ichunks);
+    const int i0 = row_begin + (int)(blockIdx.x % (unsigned)n_ichunks) * IR;
+    const int in = min(IR, row_end - i0);
+    for (int r = tid; r < N + IR + 1; r += 256) {
+        const bool is_j = r < N;
+        const int res = is_j ? r : i0 + (r - N);
+        uint32_t bits = 0;
+        if (is_j || (r - N) < in) {
+            if (amask) {
+                const uint8_t* m = amask + ((size_t)b * N + res) * A;
+#pragma unroll
+                for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+            } else {
+                bits = (1u << A) - 1u;
+            }
+        }
+        smask[r] = bits;
+    }
+    __syncthreads();
+
+    const unsigned row_bytes = (unsigned)N * AA;
+    const size_t beg = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * row_bytes;   // first byte of the block
+    const unsigned len = (unsigned)in * row_bytes;
+    const unsigned head = (unsigned)((16u - (unsigned)(beg & 15u)) & 15u);                   // bytes before the first whole slot
+    const unsigned nslots = len > head ? (len - head) >> 4 : 0u;
+    const float rcp_row = 1.0f / (float)row_bytes;
+
+    // the 16 bits starting at byte offset `off` of the block (off < len); bits past the end of the block come back 0
+    auto window = [&](unsigned off) -> uint32_t {
+        unsigned il = udiv_rcp(off, row_bytes, rcp_row);
+        const unsigned r1 = off - il * row_bytes;
+        unsigned j = r1 / AA;
+        const unsigned r = r1 - j * AA;
+        const unsigned a = r / A, c = r - a * A;
+        uint32_t win = 0;
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            const int sh = m * A - (int)c;
+            if (sh < 16) {
+                const unsigned am = a + m, dp = am / A;
+                unsigned jj = j + dp, ii = il;
+                if (jj >= (unsigned)N) {   // past the last column residue: the next row's first pairs
+                    jj -= (unsigned)N;
+                    ++ii;
+                }
+                const uint32_t mi = smi[min(ii, (unsigned)IR)];   // the guard row holds 0
+                const uint32_t bits = ((mi >> (am - dp * A)) & 1u) ? smj[jj] : 0u;
+                win |= sh <= 0 ? (bits >> (-sh)) : (bits << sh);
+            }
+        }
+        return win & 0xFFFFu;
+    };
+
+    uint8_t* o = dmask + beg;
+    for (unsigned sl = tid; sl < nslots; sl += 256) {
+        const unsigned off = head + 16u * sl;
+        const uint32_t win = window(off);
+        store16<false>(o + off, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                                           spread4((win >> 12) & 15u)));
+    }
+    // ragged head [0, head) and tail [head + 16 nslots, len): one byte per lane
+    const unsigned tail0 = head + 16u * nslots;
+    if ((unsigned)tid < 32u) {
+        const bool is_tail = tid >= 16;
+        const unsigned t = (unsigned)tid & 15u;
+        const unsigned off = is_tail ? tail0 + t : t;
+        const bool live = is_tail ? off < len : (t < head && t < len);
+        if (live) o[off] = (uint8_t)(window(off) & 1u);
     }
 }
 
@@ -1826,8 +1914,26 @@ bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, i
 // Odd small atom counts: only lengths with N % 16 == 0 (every row run 16-byte aligned in both planes).
 bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
     if (g.variant != 0 || g.flat != 1) return false;
-    if ((A != 3 && A != 5) || N % 16 != 0) return false;
+    // N % 16 == 0: both planes aligned (one launch).  N % 4 == 0: the distance plane is aligned and the mask plane
+    // goes through k1_mask_rows (a second launch on the same stream); its LDS image holds all N column masks.
+    if ((A != 3 && A != 5) || N % 4 != 0 || N > 8192) return false;
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
+template <int A>
+int launch_mask_rows(const uint8_t* amask, uint8_t* dmask, int B, int N, int row_begin, int row_end, int out_rows,
+                     int out_row_origin, hipStream_t s) {
+    const int rows = row_end - row_begin;
+    // rows per workgroup: ~64 KB of mask bytes, at least 1, at most 32
+    int IR = (int)(65536 / ((long long)N * A * A));
+    IR = IR < 1 ? 1 : (IR > 32 ? 32 : IR);
+    if (IR > rows) IR = rows;
+    const int n_ichunks = (rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_ichunks * B;
+    if (n_wg > 0x7FFFFFFFull || (unsigned long long)IR * N * A * A > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(N + IR + 1) * sizeof(uint32_t);
+    return ps_launch(k1_mask_rows<A>, dim3((unsigned)n_wg), dim3(256), lds, s, amask, dmask, N, row_begin, row_end,
+                     out_rows, out_row_origin, IR, n_ichunks);
 }
 
 template <int A>
@@ -1841,11 +1947,21 @@ int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, f
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
     const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + 2 + IR) * sizeof(uint32_t);
-    if (g.exact_sqrt)
-        return ps_launch(k1_pairdist_rowtile_odd<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist,
-                         dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
-    return ps_launch(k1_pairdist_rowtile_odd<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask,
-                     N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+    // mask plane: inside the row-tile kernel when its row runs are 16-byte aligned too, else by k1_mask_rows
+    const bool mask_inside = (N % 16 == 0);
+    uint8_t* dm = mask_inside ? dmask : nullptr;
+    int rc = 0;
+    if (dist || dm) {
+        if (g.exact_sqrt)
+            rc = ps_launch(k1_pairdist_rowtile_odd<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm,
+                           N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+        else
+            rc = ps_launch(k1_pairdist_rowtile_odd<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm,
+                           N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+    }
+    if (rc == 0 && dmask && !mask_inside)
+        rc = launch_mask_rows<A>(amask, dmask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+    return rc;
 }
 
 template <int A>

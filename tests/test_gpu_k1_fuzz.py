@@ -31,6 +31,8 @@ def test_k1_fast_kernels_differential_fuzz():
             N = int(rng.integers(16, nmax + 1))
             if A in (3, 5) and trial % 3 == 0:
                 N = 16 * int(rng.integers(1, nmax // 16 + 1))     # aligned lengths take the odd row-tile kernel
+            elif A in (3, 5) and trial % 3 == 1:
+                N = 4 * int(rng.integers(4, nmax // 4 + 1))       # N % 4 == 0: row-tile distances + k1_mask_rows
             g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
             xyz = torch.randn(B, N, A, 3, generator=g) * float(rng.choice([1.0, 10.0]))
             mask = torch.rand(B, N, A, generator=g) < float(rng.choice([0.5, 0.9, 1.0]))
