@@ -1357,7 +1357,7 @@ struct RowTileOdd {
     static constexpr int MP = (16 + AA - 2) / AA + 1;    // column residues a mask slot can touch (A = 3: 3, A = 5: 2)
 };
 
-template <int A, bool EXACT>
+template <int A, bool EXACT, bool PHASED>
 __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __restrict__ xyz,
                                                                const uint8_t* __restrict__ amask,
                                                                float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -1366,6 +1366,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
                                                                int xcd_remap) {
     using T = RowTileOdd<A>;
     constexpr int AA = T::AA, JT = T::JT;
+    static_assert(AA % 4 == 1, "the phase of a row is (R * N) mod 4 only because A*A = 1 (mod 4)");
     extern __shared__ __attribute__((aligned(16))) char smem_ro[];
     float4* sxj = reinterpret_cast<float4*>(smem_ro);           // [JT * A]
     float4* sxi = sxj + JT * A;                                  // [IR * A]
@@ -1376,11 +1377,29 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
     unsigned w = blockIdx.x;
     if (xcd_remap) w = (w & 7u) * (gridDim.x >> 3) + (w >> 3);
     const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
-    const int b = (int)(rest / (unsigned)n_ichunks);
     const int j0 = (int)tile * JT;
-    const int jn = min(JT, N - j0);   // a multiple of 4 (N % 4 == 0, JT % 16 == 0); of 16 whenever the mask is written here
-    const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
-    const int in = min(IR, row_end - i0);
+    const int jn = min(JT, N - j0);   // whole tiles are a multiple of 16 residues; the last one is whatever is left
+    // Rows of this workgroup.  Aligned lengths (N % 4 == 0): IR consecutive rows, every row run starts 16-byte aligned.
+    // PHASED (any other N): the run of absolute row R = b * out_rows + (i - origin) starts ph = (R * N) mod 4 floats past
+    // a 16-byte boundary, so a workgroup takes rows of ONE residue class of R mod 4 (every fourth row): the same ph,
+    // hence the same per-lane pattern, in all of them.
+    int b, i0, in, ph = 0;
+    constexpr int STEP = PHASED ? 4 : 1;
+    if (PHASED) {
+        b = (int)(rest / (unsigned)(4 * n_ichunks));
+        const unsigned r2 = rest % (unsigned)(4 * n_ichunks);
+        const int rho = (int)(r2 / (unsigned)n_ichunks), chunk = (int)(r2 % (unsigned)n_ichunks);
+        const long long Rb = (long long)b * out_rows - out_row_origin;          // R = Rb + i, and Rb + row_begin >= 0
+        const int first = row_begin + (int)(((rho - (int)((Rb + row_begin) & 3)) + 4) & 3);
+        i0 = first + 4 * chunk * IR;
+        in = i0 < row_end ? min(IR, (row_end - i0 + 3) >> 2) : 0;
+        if (in <= 0) return;   // uniform: this class has fewer chunks than the largest one
+        ph = (int)((((Rb + i0) & 3) * (long long)(N & 3)) & 3);
+    } else {
+        b = (int)(rest / (unsigned)n_ichunks);
+        i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
+        in = min(IR, row_end - i0);
+    }
 
     {
         const float* gj = xyz + ((size_t)b * N + j0) * (A * 3);
@@ -1389,11 +1408,11 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
             const int atom = f / 3, comp = f - atom * 3;
             lj[atom * 4 + comp] = gj[f];
         }
-        const float* gi = xyz + ((size_t)b * N + i0) * (A * 3);
         float* li = reinterpret_cast<float*>(sxi);
         for (int f = tid; f < in * (A * 3); f += 256) {
-            const int atom = f / 3, comp = f - atom * 3;
-            li[atom * 4 + comp] = gi[f];
+            const int il = f / (A * 3), g = f - il * (A * 3);
+            const int atom = g / 3, comp = g - atom * 3;
+            li[(il * A + atom) * 4 + comp] = xyz[((size_t)b * N + i0 + STEP * il) * (A * 3) + g];
         }
         for (int r = tid; r < JT + 2 + IR; r += 256) {
             const bool is_j = r < JT + 2;
@@ -1402,7 +1421,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
             uint32_t bits = 0;
             if (valid) {
                 if (amask) {
-                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A;
+                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 + rl : i0 + STEP * rl)) * A;
 #pragma unroll
                     for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
                 } else {
@@ -1415,42 +1434,54 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
     __syncthreads();
 
     const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;
-    const size_t row_stride = (size_t)N * AA;
-    const int nslots = jn * AA / 4;    // whole slots: jn % 4 == 0
+    const size_t row_stride = (size_t)STEP * N * AA;
+    const int nel = jn * AA;                   // elements of this tile's run of one row
+    const int nslots = (nel + ph + 3) >> 2;    // 16-byte slots that touch it (aligned lengths: exactly nel / 4)
 
     if (dist) {
+        // slot s covers tile elements t = 4 s - ph + kk; elements outside [0, nel) belong to the neighbouring tile or row
         float4 q[T::SPL][4];
         unsigned ai[T::SPL][4];
-        bool act[T::SPL];
+        unsigned vm[T::SPL];   // bit kk: element kk of the slot is this tile's
 #pragma unroll
         for (int u = 0; u < T::SPL; ++u) {
-            const unsigned sl = (unsigned)tid + 256u * u;
-            act[u] = (int)sl < nslots;
+            const int sl = tid + 256 * u;
+            vm[u] = 0;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const unsigned e = act[u] ? 4u * sl + kk : 0u;
+                const int t = 4 * sl - ph + kk;
+                const bool ok = sl < nslots && t >= 0 && t < nel;
+                vm[u] |= (ok ? 1u : 0u) << kk;
+                const unsigned e = ok ? (unsigned)t : 0u;
                 const unsigned j = e / AA, r = e - j * AA;
                 ai[u][kk] = r / A;
                 q[u][kk] = sxj[j * A + (r - ai[u][kk] * A)];   // column atom of this element: registers for all rows
             }
         }
-        float* o = dist + row0 * AA + 4u * tid;
+        float* o = dist + row0 * AA + (4 * tid - ph);   // 16-byte aligned: the run starts ph floats past a boundary
         for (int il = 0; il < in; ++il) {
 #pragma unroll
             for (int u = 0; u < T::SPL; ++u) {
                 const float4* xi = sxi + il * A;
-                uint4 v;
-                v.x = __float_as_uint(dist_pp<EXACT>(xi[ai[u][0]], q[u][0]));
-                v.y = __float_as_uint(dist_pp<EXACT>(xi[ai[u][1]], q[u][1]));
-                v.z = __float_as_uint(dist_pp<EXACT>(xi[ai[u][2]], q[u][2]));
-                v.w = __float_as_uint(dist_pp<EXACT>(xi[ai[u][3]], q[u][3]));
-                if (act[u]) store16<false>(o + 1024 * u, v);
+                float v[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) v[kk] = dist_pp<EXACT>(xi[ai[u][kk]], q[u][kk]);
+                float* ou = o + 1024 * u;
+                if (vm[u] == 15u) {
+                    store16<false>(ou, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                  __float_as_uint(v[3])));
+                } else if (PHASED && vm[u]) {   // a slot shared with the neighbouring tile / row: element stores
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        if ((vm[u] >> kk) & 1u) ou[kk] = v[kk];
+                }
             }
             o += row_stride;
         }
     }
 
-    if (dmask) {
+    if (dmask && !PHASED) {
+        // (aligned lengths with N % 16 == 0 only; every other case writes the mask plane with k1_mask_rows)
         // MS (<= 128) mask slots per row: lane t takes slot t % 128 of the rows with parity t / 128
         const int ms = tid & 127, par = tid >> 7;
         if (ms < jn * AA / 16) {
@@ -1914,9 +1945,10 @@ bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, i
 // Odd small atom counts: only lengths with N % 16 == 0 (every row run 16-byte aligned in both planes).
 bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
     if (g.variant != 0 || g.flat != 1) return false;
-    // N % 16 == 0: both planes aligned (one launch).  N % 4 == 0: the distance plane is aligned and the mask plane
-    // goes through k1_mask_rows (a second launch on the same stream); its LDS image holds all N column masks.
-    if ((A != 3 && A != 5) || N % 4 != 0 || N > 8192) return false;
+    // Any length.  N % 16 == 0: both planes aligned, one launch.  N % 4 == 0: the distance plane is aligned, the mask
+    // plane goes through k1_mask_rows.  Any other N: the distance rows are taken in four phase classes (PHASED) and the
+    // mask plane again goes through k1_mask_rows, whose LDS image holds all N column masks.
+    if ((A != 3 && A != 5) || N < 1 || N > 8192) return false;
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
@@ -1941,9 +1973,11 @@ int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, f
                        int N, int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
     constexpr int JT = RowTileOdd<A>::JT;
     const int rows = row_end - row_begin;
-    const int IR = rows < 32 ? rows : 32;
-    const int n_tiles = (N + JT - 1) / JT, n_ichunks = (rows + IR - 1) / IR;
-    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
+    const bool phased = (N % 4 != 0);
+    const int class_rows = phased ? (rows + 3) / 4 : rows;     // rows of the largest phase class
+    const int IR = class_rows < 32 ? class_rows : 32;
+    const int n_tiles = (N + JT - 1) / JT, n_ichunks = (class_rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * (phased ? 4 : 1) * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
     const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + 2 + IR) * sizeof(uint32_t);
@@ -1952,12 +1986,12 @@ int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, f
     uint8_t* dm = mask_inside ? dmask : nullptr;
     int rc = 0;
     if (dist || dm) {
-        if (g.exact_sqrt)
-            rc = ps_launch(k1_pairdist_rowtile_odd<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm,
-                           N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
-        else
-            rc = ps_launch(k1_pairdist_rowtile_odd<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm,
-                           N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+#define PS_K1_RTO(EX_, PH_)                                                                                        \
+    ps_launch(k1_pairdist_rowtile_odd<A, EX_, PH_>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm, N, \
+              row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap)
+        if (phased) rc = g.exact_sqrt ? PS_K1_RTO(true, true) : PS_K1_RTO(false, true);
+        else rc = g.exact_sqrt ? PS_K1_RTO(true, false) : PS_K1_RTO(false, false);
+#undef PS_K1_RTO
     }
     if (rc == 0 && dmask && !mask_inside)
         rc = launch_mask_rows<A>(amask, dmask, B, N, row_begin, row_end, out_rows, out_row_origin, s);

@@ -96,7 +96,7 @@ def test_k1_vs_oracle(SB, B, N):
     assert torch.equal(m.cpu(), rm)
 
 
-@pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12), (4, 9), (4, 131), (8, 33), (8, 7), (5, 32), (3, 16), (5, 20), (3, 28)])
+@pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12), (4, 9), (4, 131), (8, 33), (8, 7), (5, 32), (3, 16), (5, 20), (3, 28), (5, 21), (3, 18), (5, 7)])
 def test_k1_special_values(SB, A, N):
     """Infinite, huge, tiny, NaN and signed-zero coordinates propagate exactly as in the reference's arithmetic
     (protstruc.py:477-479: difference, square, sum, square root; nothing is masked or clamped): NaN and inf positions
@@ -273,7 +273,9 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              # odd row-tile kernel (A = 3, 5 with N % 16 == 0): one tile, partial last tile, several tiles
              (2, 32, 5), (1, 160, 5), (2, 240, 5), (2, 16, 3), (1, 224, 3), (1, 448, 3),
              # N % 4 == 0 but not % 16: distances by the odd row-tile kernel, mask plane by k1_mask_rows
-             (2, 20, 5), (3, 100, 5), (2, 500, 5), (2, 36, 3), (1, 228, 3), (3, 44, 3)]
+             (2, 20, 5), (3, 100, 5), (2, 500, 5), (2, 36, 3), (1, 228, 3), (3, 44, 3),
+             # any other N: distance rows in four alignment-phase classes (odd N, N % 4 == 2, tiny N)
+             (2, 17, 5), (3, 101, 5), (2, 499, 5), (2, 30, 5), (2, 19, 3), (1, 229, 3), (2, 6, 3), (2, 3, 5), (4, 2, 5)]
     try:
         for (B, N, A), flat in [(c, f) for c in cases
                              for f in ((1, 3, 4) if c[2] in (3, 4, 5, 8) else (3, 4) if c[2] in (14, 15, 16, 25, 37) else (3,))]:

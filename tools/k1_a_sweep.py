@@ -15,7 +15,7 @@ for kv in sys.argv[1:]:
     else: _lib.set_tuning("k1_" + k, int(v))
 g = torch.Generator().manual_seed(0)
 rows = []
-for A, N in [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4, 500), (5, 512), (5, 500), (8, 256), (3, 512), (3, 500), (16, 256), (25, 128)]:
+for A, N in [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4, 500), (5, 512), (5, 500), (5, 501), (8, 256), (3, 512), (3, 500), (3, 501), (16, 256), (25, 128)]:
     B = max(1, int(8e9 / (N * N * A * A * 5)))
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
