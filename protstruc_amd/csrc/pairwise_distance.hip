@@ -1388,7 +1388,10 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __re
     if (PHASED) {
         b = (int)(rest / (unsigned)(4 * n_ichunks));
         const unsigned r2 = rest % (unsigned)(4 * n_ichunks);
-        const int rho = (int)(r2 / (unsigned)n_ichunks), chunk = (int)(r2 % (unsigned)n_ichunks);
+        // class fastest: the four classes of one block of 4 * IR rows run next to each other in time, so that block of
+        // the output is written as a whole (with the class as the outer index the distance plane of A = 5, N = 501 ran
+        // at 3.97 TB/s instead of 4.89)
+        const int rho = (int)(r2 & 3u), chunk = (int)(r2 >> 2);
         const long long Rb = (long long)b * out_rows - out_row_origin;          // R = Rb + i, and Rb + row_begin >= 0
         const int first = row_begin + (int)(((rho - (int)((Rb + row_begin) & 3)) + 4) & 3);
         i0 = first + 4 * chunk * IR;
