@@ -37,7 +37,7 @@ extern "C" {
 #define PS_RNG_STATE_WORDS 528
 
 /* ABI version of this header (bumped on any signature change); ps_abi_version() returns the library's. */
-#define PS_ABI_VERSION 2
+#define PS_ABI_VERSION 3
 int ps_abi_version(void);
 
 /* 0 for the product library.  1 for builds made with -DPS_EXPERIMENTS (tools/ only), which contain timing
@@ -116,6 +116,32 @@ int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask,
                                  int row_begin, int row_end,
                                  int out_rows, int out_row_origin,
                                  const ps_k1_config* cfg, void* stream);
+
+/*
+ * Which K1 kernel a launch with these arguments takes -- a pure host query, nothing is launched and no device memory is
+ * touched.  It runs the launcher's OWN dispatcher in a record-only mode (same eligibility predicates, same grid and LDS
+ * arithmetic), so the answer cannot drift from what ps_pairwise_distance_cfg_f32 does.  `dist_misalign` /
+ * `mask_misalign`: address of the plane modulo 16 (0 for anything torch.empty returns), or -1 when that plane is not
+ * requested (NULL); `has_atom_mask`: whether atom_mask would be non-NULL.  Argument errors are the launcher's
+ * (hipErrorInvalidValue).  No reference counterpart: it exists so that benchmarks and tests can name the kernel that ran
+ * and assert that every kernel family is reached by some tested shape.
+ */
+typedef struct ps_k1_plan {
+    int struct_size;            /* in: sizeof(ps_k1_plan) */
+    int n_launches;             /* 0 (empty input), 1, or 2 (distance plane + k1_mask_rows) */
+    char family[48];            /* "pattern" | "flat" | "flatA" | "flatS" | "rowtile" | "rowtile_odd" | "rowtile_odd_phased" |
+                                   "anyA" | "slot_decode" | "element" | ..., a second launch appended as " + mask_rows" */
+    char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<128>" */
+    unsigned n_workgroups;      /* grid of the first launch */
+    unsigned lds_bytes;         /* static + dynamic LDS per workgroup of the first launch */
+    int threads_per_workgroup;
+    unsigned n_workgroups_2;    /* second launch, if any */
+    unsigned lds_bytes_2;
+} ps_k1_plan;
+
+int ps_k1_plan_f32(int B, int N, int A, int row_begin, int row_end, int out_rows, int out_row_origin,
+                   int dist_misalign, int mask_misalign, int has_atom_mask,
+                   const ps_k1_config* cfg, ps_k1_plan* plan);
 
 /*
  * K2 -- replaces StructureBatch.backbone_dihedrals together with

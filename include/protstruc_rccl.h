@@ -44,8 +44,9 @@ int ps_comm_destroy(ps_comm* comm);
 int ps_comm_rank(const ps_comm* comm, int* rank_out, int* world_out);
 
 /* Rows [lo, hi) of `n_rows` that belong to `rank` of `world`: lo = n_rows*rank/world, hi = n_rows*(rank+1)/world
- * (the split every launcher-side caller must use for row_begin / row_end). */
-void ps_shard_rows(int n_rows, int rank, int world, int* lo_out, int* hi_out);
+ * (the split every launcher-side caller must use for row_begin / row_end).  Precondition: n_rows >= 0, world >= 1,
+ * 0 <= rank < world; anything else returns hipErrorInvalidValue with lo = hi = 0 (never a division by zero). */
+int ps_shard_rows(int n_rows, int rank, int world, int* lo_out, int* hi_out);
 
 /*
  * In-place all-gather of row slices.  `full` is this rank's (B, n_rows, row_bytes) buffer, contiguous, of which it
@@ -53,9 +54,15 @@ void ps_shard_rows(int n_rows, int rank, int world, int* lo_out, int* hi_out);
  * every rank's rows.  A rank's slice of one structure is one contiguous run, so the exchange is B collectives
  * issued as ONE group (ncclGroupStart / ncclGroupEnd): in-place ncclAllGather per structure when n_rows % world == 0
  * (rank r's rows sit at offset r * count of the receive buffer, the layout RCCL's in-place form expects), else one
- * in-place ncclBroadcast per (structure, owner).  world == 1 is a no-op.
+ * in-place ncclBroadcast per (structure, owner).  A one-rank communicator is NOT short-cut: it issues the same group
+ * (a self-gather moves nothing), so one GPU exercises every RCCL call a multi-GPU run makes.
  */
 int ps_allgather_rows(ps_comm* comm, void* full, int B, int n_rows, long long row_bytes, void* stream);
+
+/* The same with flags: PS_GATHER_FORCE_BROADCAST takes the per-(structure, owner) ncclBroadcast form even when
+ * n_rows % world == 0 (same bits; lets a test or an A/B run reach the uneven-split branch at any shape). */
+#define PS_GATHER_FORCE_BROADCAST 1
+int ps_allgather_rows_ex(ps_comm* comm, void* full, int B, int n_rows, long long row_bytes, int flags, void* stream);
 
 const char* ps_comm_error_string(int code);
 

@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PROTSTRUC_AMD_LIB selects another build of the same sources (tools/ use the -DPS_EXPERIMENTS one)
 LIB_PATH = os.environ.get("PROTSTRUC_AMD_LIB") or os.path.join(_HERE, "lib", "libprotstruc_hip.so")
-EXPECTED_ABI = 2  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
+EXPECTED_ABI = 3  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
 
 
 class K1Config(ctypes.Structure):
@@ -18,6 +18,13 @@ class K1Config(ctypes.Structure):
     _fields_ = [(name, ctypes.c_int) for name in (
         "struct_size", "exact_sqrt", "variant", "flat", "rows_per_block", "lds_pad_kb", "flat_cpw",
         "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "anya_fl_log2", "experiment")]
+
+
+class K1Plan(ctypes.Structure):
+    """``ps_k1_plan`` of include/protstruc_hip.h, field for field."""
+    _fields_ = [("struct_size", ctypes.c_int), ("n_launches", ctypes.c_int), ("family", ctypes.c_char * 48),
+                ("kernel", ctypes.c_char * 96), ("n_workgroups", ctypes.c_uint), ("lds_bytes", ctypes.c_uint),
+                ("threads_per_workgroup", ctypes.c_int), ("n_workgroups_2", ctypes.c_uint), ("lds_bytes_2", ctypes.c_uint)]
 
 
 _c_f32p = ctypes.c_void_p
@@ -35,6 +42,7 @@ SIGNATURES = {
                                           _c_int, _c_int, _c_stream]),
     "ps_pairwise_distance_cfg_f32": (_c_int, [_c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_int, _c_int, _c_int, _c_int, _c_int,
                                               _c_int, _c_int, ctypes.POINTER(K1Config), _c_stream]),
+    "ps_k1_plan_f32": (_c_int, [_c_int] * 10 + [ctypes.POINTER(K1Config), ctypes.POINTER(K1Plan)]),
     "ps_backbone_dihedrals_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_u8p, _c_u8p, _c_int, _c_int,
                                            _c_int, _c_stream]),
     "ps_pairwise_angles_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
@@ -190,6 +198,23 @@ def k1_config(device=None, **overrides):
             return cfg
     d.update(overrides)
     return K1Config(**d)
+
+
+def k1_plan(B, N, A, row_begin=0, row_end=None, *, compact=False, dist_misalign=0, mask_misalign=0, has_atom_mask=True,
+            device=None, **overrides):
+    """Which kernel ``ps_pairwise_distance_cfg_f32`` takes for this shape under ``device``'s current configuration
+    (fields overridden by keyword): a dict with ``family``, ``kernel``, ``n_launches``, ``n_workgroups``, ``lds_bytes``.
+    Pure host query (``ps_k1_plan_f32``): the library runs its own dispatcher in record-only mode."""
+    row_end = N if row_end is None else row_end
+    out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
+    plan = K1Plan(struct_size=ctypes.sizeof(K1Plan))
+    cfg = k1_config(device, **overrides)
+    check(load().ps_k1_plan_f32(B, N, A, row_begin, row_end, out_rows, origin, dist_misalign, mask_misalign,
+                                int(bool(has_atom_mask)), ctypes.byref(cfg), ctypes.byref(plan)), "ps_k1_plan_f32")
+    return {"family": plan.family.decode(), "kernel": plan.kernel.decode(), "n_launches": plan.n_launches,
+            "n_workgroups": plan.n_workgroups, "lds_bytes": plan.lds_bytes,
+            "threads_per_workgroup": plan.threads_per_workgroup,
+            **({"n_workgroups_2": plan.n_workgroups_2, "lds_bytes_2": plan.lds_bytes_2} if plan.n_launches > 1 else {})}
 
 
 def set_tuning(key, value, device=None):

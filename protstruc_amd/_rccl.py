@@ -11,8 +11,9 @@ from ._lib import HipLibraryError
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libprotstruc_rccl.so")
-EXPECTED_ABI = 1
+EXPECTED_ABI = 2
 COMM_ID_BYTES = 128
+GATHER_FORCE_BROADCAST = 1   # PS_GATHER_FORCE_BROADCAST
 
 _vp, _int = ctypes.c_void_p, ctypes.c_int
 SIGNATURES = {
@@ -22,8 +23,9 @@ SIGNATURES = {
     "ps_comm_create": (_int, [ctypes.POINTER(_vp), _vp, _int, _int]),
     "ps_comm_destroy": (_int, [_vp]),
     "ps_comm_rank": (_int, [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
-    "ps_shard_rows": (None, [_int, _int, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
+    "ps_shard_rows": (_int, [_int, _int, _int, ctypes.POINTER(_int), ctypes.POINTER(_int)]),
     "ps_allgather_rows": (_int, [_vp, _vp, _int, _int, ctypes.c_longlong, _vp]),
+    "ps_allgather_rows_ex": (_int, [_vp, _vp, _int, _int, ctypes.c_longlong, _int, _vp]),
     "ps_comm_error_string": (ctypes.c_char_p, [_int]),
 }
 

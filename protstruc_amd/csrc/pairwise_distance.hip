@@ -29,6 +29,8 @@
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
+#include <cstdio>
+#include <cstring>
 #include <type_traits>
 
 namespace {
@@ -1858,9 +1860,53 @@ __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restri
     }
 }
 
+// ---- launch context: the dispatcher either launches or only RECORDS what it would launch (ps_k1_plan_f32) ----
+// Every K1 launch goes through k1_go, so the plan a caller reads is by construction the dispatch a launch takes: same
+// predicates, same grid, same LDS size -- there is no second copy of the selection logic to drift.
+struct K1Go {
+    hipStream_t s;
+    ps_k1_plan* plan;   // non-null: record only, launch nothing
+};
+
+inline void plan_append(char* dst, size_t cap, const char* text) {
+    size_t n = strlen(dst);
+    if (n && n + 3 < cap) {
+        memcpy(dst + n, " + ", 4);
+        n += 3;
+    }
+    for (size_t i = 0; text[i] && n + 1 < cap; ++i) dst[n++] = text[i];
+    dst[n] = 0;
+}
+
+template <typename... KArgs, typename... Args>
+inline int k1_go(const K1Go& go, const char* family, const char* name, int tparam, void (*kernel)(KArgs...), dim3 grid,
+                 dim3 block, size_t lds, Args&&... args) {
+    if (!go.plan) return ps_launch(kernel, grid, block, lds, go.s, static_cast<Args&&>(args)...);
+    ps_k1_plan& pl = *go.plan;
+    char full[64];
+    if (tparam >= 0) snprintf(full, sizeof full, "%s<%d>", name, tparam);
+    else snprintf(full, sizeof full, "%s", name);
+    plan_append(pl.kernel, sizeof pl.kernel, full);
+    plan_append(pl.family, sizeof pl.family, family);
+    hipFuncAttributes fa;
+    unsigned static_lds = 0;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess) static_lds = (unsigned)fa.sharedSizeBytes;
+    const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
+    if (pl.n_launches == 0) {
+        pl.n_workgroups = (unsigned)(n_wg > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_wg);
+        pl.lds_bytes = (unsigned)lds + static_lds;
+        pl.threads_per_workgroup = (int)(block.x * block.y * block.z);
+    } else {
+        pl.n_workgroups_2 = (unsigned)(n_wg > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_wg);
+        pl.lds_bytes_2 = (unsigned)lds + static_lds;
+    }
+    ++pl.n_launches;
+    return 0;
+}
+
 template <int JT>
 int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
-               int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+               int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     const int IR = g.rows_per_block;
     const int rows = row_end - row_begin;
     dim3 grid((N + JT - 1) / JT, (rows + IR - 1) / IR, B);
@@ -1869,8 +1915,8 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
     const bool ma = (N % 16 == 0) && ((reinterpret_cast<uintptr_t>(dmask) & 15) == 0);
     const bool ex = g.exact_sqrt != 0;
 #define PS_K1_LAUNCH1(NT_, DA_, MA_, EX_)                                                                         \
-    ps_launch(k1_pairdist_a15<JT, NT_, DA_, MA_, EX_>, grid, dim3(256), lds, s, xyz, amask, dist, dmask, N,       \
-              row_begin, row_end, out_rows, out_row_origin, IR)
+    k1_go(go, "slot_decode", "k1_pairdist_a15", JT, k1_pairdist_a15<JT, NT_, DA_, MA_, EX_>, grid, dim3(256), lds, xyz, \
+          amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR)
 #define PS_K1_LAUNCH(NT_, DA_, MA_) (ex ? PS_K1_LAUNCH1(NT_, DA_, MA_, true) : PS_K1_LAUNCH1(NT_, DA_, MA_, false))
     if (da && ma && g.variant == 0) {
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
@@ -1879,8 +1925,9 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
         const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
 #define PS_K1_PAT(NT_, M_, U_)                                                                                    \
-    ps_launch(k1_pairdist_a15_pat<JT, NT_, M_, U_>, dim3((unsigned)n_wg), dim3(256), lds_pat, s, xyz, amask,      \
-              dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, (int)grid.x, (int)grid.y, remap)
+    k1_go(go, "pattern", "k1_pairdist_a15_pat", JT, k1_pairdist_a15_pat<JT, NT_, M_, U_>, dim3((unsigned)n_wg),   \
+          dim3(256), lds_pat, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR,       \
+          (int)grid.x, (int)grid.y, remap)
 #ifdef PS_EXPERIMENTS
         const int math = g.experiment & 15;
         const bool unroll = (g.experiment & 16) != 0;
@@ -1912,7 +1959,7 @@ bool flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int 
 
 int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
                     int N, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
-                    unsigned range_stride, hipStream_t s) {
+                    unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     // chunks per range: exact for one range, an upper bound when the ranges start at different 128-pair phases
     const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> 7) - (pbeg >> 7) : ((pend - pbeg) >> 7) + 2;
@@ -1926,8 +1973,9 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
     const size_t pad = (size_t)g.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap
 #define PS_K1_FLAT(EX_, HM_)                                                                                      \
-    ps_launch(k1_pairdist_a15_flat<EX_, HM_>, dim3(n_wg), dim3(256), pad, s, xyz, amask, dist, dmask, B, N,       \
-              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
+    k1_go(go, "flat", "k1_pairdist_a15_flat", -1, k1_pairdist_a15_flat<EX_, HM_>, dim3(n_wg), dim3(256), pad, xyz, \
+          amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw,  \
+          remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_FLAT(true, true) : PS_K1_FLAT(true, false);
     return amask ? PS_K1_FLAT(false, true) : PS_K1_FLAT(false, false);
 #undef PS_K1_FLAT
@@ -1957,7 +2005,7 @@ bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmas
 
 template <int A>
 int launch_mask_rows(const uint8_t* amask, uint8_t* dmask, int B, int N, int row_begin, int row_end, int out_rows,
-                     int out_row_origin, hipStream_t s) {
+                     int out_row_origin, const K1Go& go) {
     const int rows = row_end - row_begin;
     // rows per workgroup: ~64 KB of mask bytes, at least 1, at most 32
     int IR = (int)(65536 / ((long long)N * A * A));
@@ -1967,13 +2015,13 @@ int launch_mask_rows(const uint8_t* amask, uint8_t* dmask, int B, int N, int row
     const unsigned long long n_wg = (unsigned long long)n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull || (unsigned long long)IR * N * A * A > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)(N + IR + 1) * sizeof(uint32_t);
-    return ps_launch(k1_mask_rows<A>, dim3((unsigned)n_wg), dim3(256), lds, s, amask, dmask, N, row_begin, row_end,
-                     out_rows, out_row_origin, IR, n_ichunks);
+    return k1_go(go, "mask_rows", "k1_mask_rows", A, k1_mask_rows<A>, dim3((unsigned)n_wg), dim3(256), lds, amask, dmask,
+                 N, row_begin, row_end, out_rows, out_row_origin, IR, n_ichunks);
 }
 
 template <int A>
 int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
-                       int N, int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+                       int N, int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     constexpr int JT = RowTileOdd<A>::JT;
     const int rows = row_end - row_begin;
     const bool phased = (N % 4 != 0);
@@ -1990,20 +2038,21 @@ int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, f
     int rc = 0;
     if (dist || dm) {
 #define PS_K1_RTO(EX_, PH_)                                                                                        \
-    ps_launch(k1_pairdist_rowtile_odd<A, EX_, PH_>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dm, N, \
-              row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap)
+    k1_go(go, PH_ ? "rowtile_odd_phased" : "rowtile_odd", "k1_pairdist_rowtile_odd", A,                           \
+          k1_pairdist_rowtile_odd<A, EX_, PH_>, dim3((unsigned)n_wg), dim3(256), lds, xyz, amask, dist, dm, N,    \
+          row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap)
         if (phased) rc = g.exact_sqrt ? PS_K1_RTO(true, true) : PS_K1_RTO(false, true);
         else rc = g.exact_sqrt ? PS_K1_RTO(true, false) : PS_K1_RTO(false, false);
 #undef PS_K1_RTO
     }
     if (rc == 0 && dmask && !mask_inside)
-        rc = launch_mask_rows<A>(amask, dmask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+        rc = launch_mask_rows<A>(amask, dmask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
     return rc;
 }
 
 template <int A>
 int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
-                   int row_begin, int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+                   int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     constexpr int JT = RowTile<A>::JT;
     const int rows = row_end - row_begin;
     const int IR = rows < 32 ? rows : 32;              // 32 rows x 8 KB + 2 KB of mask = 320 KB per workgroup at most
@@ -2013,10 +2062,12 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
     const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
     const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + IR) * sizeof(uint32_t);
     if (g.exact_sqrt)
-        return ps_launch(k1_pairdist_rowtile<A, true>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask,
-                         N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
-    return ps_launch(k1_pairdist_rowtile<A, false>, dim3((unsigned)n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, N,
-                     row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap);
+        return k1_go(go, "rowtile", "k1_pairdist_rowtile", A, k1_pairdist_rowtile<A, true>, dim3((unsigned)n_wg), dim3(256),
+                     lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles,
+                     n_ichunks, remap);
+    return k1_go(go, "rowtile", "k1_pairdist_rowtile", A, k1_pairdist_rowtile<A, false>, dim3((unsigned)n_wg), dim3(256),
+                 lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks,
+                 remap);
 }
 
 bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
@@ -2046,7 +2097,7 @@ auto flat_kernel_of() {
 template <int A>
 int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                  int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
-                 unsigned range_stride, hipStream_t s) {
+                 unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     constexpr int L2 = FlatOf<A>::type::FL_LOG2, FLn = FlatOf<A>::type::FLn;
     const unsigned cpr = n_ranges == 1 ? ((pend + (FLn - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
@@ -2057,8 +2108,9 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_FLATA(EX_, HM_)                                                                                     \
-    ps_launch(flat_kernel_of<A, EX_, HM_>(), dim3(n_wg), dim3(256), 0, s, xyz, amask, dist, dmask, B, N,          \
-              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
+    k1_go(go, A * A <= 128 ? "flatS" : "flatA", A * A <= 128 ? "k1_pairdist_flatS" : "k1_pairdist_flatA", A,      \
+          flat_kernel_of<A, EX_, HM_>(), dim3(n_wg), dim3(256), 0, xyz, amask, dist, dmask, B, N, out_rows,       \
+          out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_FLATA(true, true) : PS_K1_FLATA(true, false);
     return amask ? PS_K1_FLATA(false, true) : PS_K1_FLATA(false, false);
 #undef PS_K1_FLATA
@@ -2077,7 +2129,7 @@ bool anyA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int 
 
 int launch_anyA_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
                      int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
-                     unsigned n_ranges, unsigned range_stride, hipStream_t s) {
+                     unsigned n_ranges, unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     // largest power of two of pairs (16..256) whose LDS image (A float4 + A*A/8 bytes of mask bits per pair) stays
     // under 25 KB: measured best or within 2 % of best for A = 4, 5, 8, 14, 16, 25, 37 (profiles/r01_k1_any_a.log)
@@ -2099,9 +2151,9 @@ int launch_anyA_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, flo
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_ANYA(EX_, HM_)                                                                                      \
-    ps_launch(k1_pairdist_anyA_flat<EX_, HM_>, dim3(n_wg), dim3(256), lds, s, xyz, amask, dist, dmask, B, N, A,   \
-              out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, fl_log2, FRr, (int)cpw, remap,  \
-              rn, rr)
+    k1_go(go, "anyA", "k1_pairdist_anyA_flat", -1, k1_pairdist_anyA_flat<EX_, HM_>, dim3(n_wg), dim3(256), lds,   \
+          xyz, amask, dist, dmask, B, N, A, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr,   \
+          fl_log2, FRr, (int)cpw, remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_ANYA(true, true) : PS_K1_ANYA(true, false);
     return amask ? PS_K1_ANYA(false, true) : PS_K1_ANYA(false, false);
 #undef PS_K1_ANYA
@@ -2138,10 +2190,12 @@ extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
     cfg->xcd_remap = 1;
 }
 
-extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask, float* dist,
-                                            uint8_t* dist_mask, int B, int N, int A, int row_begin, int row_end,
-                                            int out_rows, int out_row_origin, const ps_k1_config* cfg,
-                                            void* stream) {
+namespace {
+
+// The one dispatcher: argument checks, then the first eligible kernel family in a fixed order.  `go` decides whether the
+// chosen kernel is launched or only recorded (ps_k1_plan_f32); pointers are used for their NULL-ness and alignment only.
+int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask, int B,
+                int N, int A, int row_begin, int row_end, int out_rows, int out_row_origin, const ps_k1_config* cfg) {
     if (!xyz || (!dist && !dist_mask) || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
@@ -2152,17 +2206,16 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         g = *cfg;   // by value: the caller may change or free its copy as soon as this call returns
     }
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int rows = row_end - row_begin;
     if (rowtile_eligible(g, dist, dist_mask, A)) {
         if (A == 4)
-            return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
-        return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+            return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
+        return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (rowtile_odd_eligible(g, dist, dist_mask, N, A)) {
         if (A == 3)
-            return launch_rowtile_odd<3>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
-        return launch_rowtile_odd<5>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, s);
+            return launch_rowtile_odd<3>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
+        return launch_rowtile_odd<5>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
@@ -2171,34 +2224,34 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         const unsigned r1 = whole ? (unsigned)((unsigned long long)B * out_rows * N) : r0 + (unsigned)rows * (unsigned)N;
         const unsigned nrg = whole ? 1u : (unsigned)B, stride = whole ? 0u : (unsigned)out_rows * (unsigned)N;
         switch (A) {
-            case 3: return launch_flatA<3>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 4: return launch_flatA<4>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 5: return launch_flatA<5>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 8: return launch_flatA<8>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 14: return launch_flatA<14>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 25: return launch_flatA<25>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
-            case 37: return launch_flatA<37>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, s);
+            case 3: return launch_flatA<3>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 4: return launch_flatA<4>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 5: return launch_flatA<5>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 8: return launch_flatA<8>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 14: return launch_flatA<14>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 25: return launch_flatA<25>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 37: return launch_flatA<37>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             default: break;
         }
     }
     if ((A != A15 || g.flat == 3) && anyA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         if (rows == out_rows)
             return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,
-                                    (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
+                                    (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, go);
         const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
         return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, r0,
-                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
+                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, go);
     }
     if (A == A15 && flat_eligible(g, dist, dist_mask, B, N, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
         if (rows == out_rows)
             return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, 0u,
-                                   (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, s);
+                                   (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, go);
         const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
         return launch_a15_flat(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0,
-                               r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, s);
+                               r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, go);
     }
     // the flat kernels above and the pattern kernel run on 1-D grids and take any batch size; the slot-decode and the
     // element-per-lane kernels put the structure on grid.z (checked where they are launched)
@@ -2207,9 +2260,9 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
         const int jt = g.jt ? g.jt : (N >= 256 ? 128 : 64);
         if (jt == 128)
             return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,
-                                   out_row_origin, s);
+                                   out_row_origin, go);
         return launch_a15<64>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
-                              s);
+                              go);
     }
     if (rows > 65535 || B > 65535) return (int)hipErrorInvalidValue;   // element kernel: (row, structure) on grid.y / grid.z
     const unsigned long long nE = (unsigned long long)N * A * A;
@@ -2217,10 +2270,43 @@ extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* ato
     unsigned gx = (unsigned)((nE + 255) / 256);
     if (gx > 64) gx = 64;
     if (g.exact_sqrt)
-        return ps_launch(k1_pairdist_generic<true>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist,
-                         dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
-    return ps_launch(k1_pairdist_generic<false>, dim3(gx, rows, B), dim3(256), 0, s, xyz, atom_mask, dist, dist_mask,
-                     N, A, row_begin, row_end, out_rows, out_row_origin);
+        return k1_go(go, "element", "k1_pairdist_generic", -1, k1_pairdist_generic<true>, dim3(gx, rows, B), dim3(256), 0,
+                     xyz, atom_mask, dist, dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
+    return k1_go(go, "element", "k1_pairdist_generic", -1, k1_pairdist_generic<false>, dim3(gx, rows, B), dim3(256), 0, xyz,
+                 atom_mask, dist, dist_mask, N, A, row_begin, row_end, out_rows, out_row_origin);
+}
+
+}  // namespace
+
+extern "C" int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask, float* dist,
+                                            uint8_t* dist_mask, int B, int N, int A, int row_begin, int row_end,
+                                            int out_rows, int out_row_origin, const ps_k1_config* cfg,
+                                            void* stream) {
+    const K1Go go{reinterpret_cast<hipStream_t>(stream), nullptr};
+    return k1_dispatch(go, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, cfg);
+}
+
+extern "C" int ps_k1_plan_f32(int B, int N, int A, int row_begin, int row_end, int out_rows, int out_row_origin,
+                              int dist_misalign, int mask_misalign, int has_atom_mask, const ps_k1_config* cfg,
+                              ps_k1_plan* plan) {
+    if (!plan || plan->struct_size != (int)sizeof(ps_k1_plan)) return (int)hipErrorInvalidValue;
+    if (dist_misalign > 15 || mask_misalign > 15 || (dist_misalign >= 0 && dist_misalign % 4 != 0))
+        return (int)hipErrorInvalidValue;
+    *plan = ps_k1_plan{};
+    plan->struct_size = (int)sizeof(ps_k1_plan);
+    // stand-in addresses: never dereferenced on the host, only tested for NULL and for their low four bits
+    const uintptr_t base = 0x10000;
+    const float* xyz = reinterpret_cast<const float*>(base);
+    const uint8_t* am = has_atom_mask ? reinterpret_cast<const uint8_t*>(base) : nullptr;
+    float* d = dist_misalign < 0 ? nullptr : reinterpret_cast<float*>(base + (uintptr_t)dist_misalign);
+    uint8_t* m = mask_misalign < 0 ? nullptr : reinterpret_cast<uint8_t*>(base + (uintptr_t)mask_misalign);
+    const K1Go go{nullptr, plan};
+    const int rc = k1_dispatch(go, xyz, am, d, m, B, N, A, row_begin, row_end, out_rows, out_row_origin, cfg);
+    if (rc == 0 && plan->n_launches == 0) {
+        snprintf(plan->kernel, sizeof plan->kernel, "(nothing to launch)");
+        snprintf(plan->family, sizeof plan->family, "empty");
+    }
+    return rc;
 }
 
 extern "C" int ps_pairwise_distance_f32(const float* xyz, const uint8_t* atom_mask, float* dist, uint8_t* dist_mask,

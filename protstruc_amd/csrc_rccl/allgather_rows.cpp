@@ -18,7 +18,7 @@ namespace {
 inline int from_nccl(ncclResult_t r) { return r == ncclSuccess ? 0 : 1000 + (int)r; }
 }  // namespace
 
-extern "C" int ps_rccl_abi_version(void) { return 1; }
+extern "C" int ps_rccl_abi_version(void) { return 2; }
 
 extern "C" int ps_rccl_version(int* version) {
     if (!version) return (int)hipErrorInvalidValue;
@@ -62,15 +62,23 @@ extern "C" int ps_comm_rank(const ps_comm* comm, int* rank_out, int* world_out) 
     return 0;
 }
 
-extern "C" void ps_shard_rows(int n_rows, int rank, int world, int* lo_out, int* hi_out) {
+extern "C" int ps_shard_rows(int n_rows, int rank, int world, int* lo_out, int* hi_out) {
+    if (lo_out) *lo_out = 0;
+    if (hi_out) *hi_out = 0;
+    if (n_rows < 0 || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;  // (no division by 0)
     const long long n = n_rows;
     if (lo_out) *lo_out = (int)(n * rank / world);
     if (hi_out) *hi_out = (int)(n * (rank + 1) / world);
+    return 0;
 }
 
-extern "C" int ps_allgather_rows(ps_comm* comm, void* full, int B, int n_rows, long long row_bytes, void* stream) {
-    if (!comm || !full || B < 0 || n_rows < 0 || row_bytes < 0) return (int)hipErrorInvalidValue;
-    if (comm->world == 1 || B == 0 || n_rows == 0 || row_bytes == 0) return 0;
+extern "C" int ps_allgather_rows_ex(ps_comm* comm, void* full, int B, int n_rows, long long row_bytes, int flags,
+                                    void* stream) {
+    if (!comm || !full || B < 0 || n_rows < 0 || row_bytes < 0 || (flags & ~PS_GATHER_FORCE_BROADCAST))
+        return (int)hipErrorInvalidValue;
+    if (B == 0 || n_rows == 0 || row_bytes == 0) return 0;
+    // world == 1 is NOT short-cut: a one-rank communicator runs the same grouped collectives (a self-gather is legal
+    // in RCCL and moves nothing), so a single GPU exercises every call a multi-GPU run makes.
     int dev = -1;
     hipError_t he = hipGetDevice(&dev);
     if (he != hipSuccess) return (int)he;
@@ -83,7 +91,7 @@ extern "C" int ps_allgather_rows(ps_comm* comm, void* full, int B, int n_rows, l
     ncclResult_t r = ncclGroupStart();
     if (r != ncclSuccess) return from_nccl(r);
     ncclResult_t first_err = ncclSuccess;
-    if (n_rows % P == 0) {
+    if (n_rows % P == 0 && !(flags & PS_GATHER_FORCE_BROADCAST)) {
         const size_t count = (size_t)(n_rows / P) * (size_t)row_bytes;  // bytes per rank per structure
         for (int b = 0; b < B && first_err == ncclSuccess; ++b) {
             char* recv = base + (size_t)b * struct_bytes;
@@ -102,6 +110,10 @@ extern "C" int ps_allgather_rows(ps_comm* comm, void* full, int B, int n_rows, l
     }
     r = ncclGroupEnd();  // always closed, also after an error inside the group
     return from_nccl(first_err != ncclSuccess ? first_err : r);
+}
+
+extern "C" int ps_allgather_rows(ps_comm* comm, void* full, int B, int n_rows, long long row_bytes, void* stream) {
+    return ps_allgather_rows_ex(comm, full, B, n_rows, row_bytes, 0, stream);
 }
 
 extern "C" const char* ps_comm_error_string(int code) {

@@ -50,28 +50,42 @@ def _group_key(group):
     return (getattr(pg, "group_name", None), id(pg))
 
 
-def native_comm(group=None):
-    """The libprotstruc_rccl communicator of ``group`` (created collectively on first use: rank 0 draws the RCCL
-    unique id and ``torch.distributed`` carries it to the other ranks)."""
+def native_comm(group=None, device=None):
+    """The libprotstruc_rccl communicator of (``group``, ``device``), created collectively on first use: rank 0 draws
+    the RCCL unique id and ``torch.distributed`` carries it to the other ranks.  ``ps_comm_create`` binds the
+    communicator to the HIP device that is current when it runs, and the object broadcast on the nccl backend uses
+    the current device as well, so both happen with ``device`` (default: the current device) made current -- a caller
+    whose tensors live on cuda:LOCAL_RANK but who never called ``torch.cuda.set_device`` still gets a communicator
+    on the GPU its buffers are on."""
     from . import _rccl
 
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if device.type != "cuda":
+        raise ValueError(f"a native RCCL communicator needs a GPU, got {device}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     key = _group_key(group)
     if key in _COMMS:
-        return _COMMS[key][0]
+        comm, _pg, dev_index = _COMMS[key]
+        if dev_index != device.index:
+            raise ValueError(f"the native communicator of this process group was created on cuda:{dev_index}; "
+                             f"buffers on {device} cannot be gathered with it (one GPU per rank)")
+        return comm
     lib = _rccl.load()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    ident = [None]
-    if rank == 0:
-        buf = ctypes.create_string_buffer(_rccl.COMM_ID_BYTES)
-        _rccl.check(lib.ps_comm_unique_id(buf), "ps_comm_unique_id")
-        ident[0] = buf.raw
-    src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
-    dist.broadcast_object_list(ident, src=src, group=group)
-    comm = ctypes.c_void_p()
-    idbuf = ctypes.create_string_buffer(ident[0], _rccl.COMM_ID_BYTES)
-    _rccl.check(lib.ps_comm_create(ctypes.byref(comm), idbuf, world, rank), "ps_comm_create")
+    with torch.cuda.device(device):
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(_rccl.COMM_ID_BYTES)
+            _rccl.check(lib.ps_comm_unique_id(buf), "ps_comm_unique_id")
+            ident[0] = buf.raw
+        src = dist.get_global_rank(group, 0) if group is not None and group is not dist.group.WORLD else 0
+        dist.broadcast_object_list(ident, src=src, group=group)
+        comm = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(ident[0], _rccl.COMM_ID_BYTES)
+        _rccl.check(lib.ps_comm_create(ctypes.byref(comm), idbuf, world, rank), "ps_comm_create")
     # the group object is kept alongside: while this entry exists its id cannot be reused by a later group
-    _COMMS[key] = (comm, dist.group.WORLD if group is None else group)
+    _COMMS[key] = (comm, dist.group.WORLD if group is None else group, device.index)
     return comm
 
 
@@ -80,7 +94,7 @@ def destroy_native_comms() -> None:
     from . import _rccl
 
     while _COMMS:
-        _, (comm, _pg) = _COMMS.popitem()
+        _, (comm, _pg, _dev) = _COMMS.popitem()
         _rccl.check(_rccl.load().ps_comm_destroy(comm), "ps_comm_destroy")
 
 
@@ -96,26 +110,35 @@ def _pick_impl(impl: Optional[str], tensor: torch.Tensor, group) -> str:
     return impl
 
 
-def allgather_rows(full: torch.Tensor, group=None, impl: Optional[str] = None) -> None:
+def allgather_rows(full: torch.Tensor, group=None, impl: Optional[str] = None, *, force_broadcast: bool = False) -> None:
     """In-place all-gather of row slices of a contiguous (B, N, ...) tensor: on entry rank r holds rows
-    ``shard_rows(N, r, P)`` of every structure, on return every rank holds all rows."""
+    ``shard_rows(N, r, P)`` of every structure, on return every rank holds all rows.
+
+    With one rank and no explicit ``impl`` there is nothing to exchange and nothing is called.  An EXPLICIT
+    ``impl="native"`` / ``"torch"`` always issues the collectives, also at world 1 (a self-gather is legal and moves
+    nothing): that is how a single GPU executes exactly the calls a multi-GPU run makes.  ``force_broadcast`` takes
+    the per-(structure, owner) broadcast form that uneven splits use, whatever N is (same bits)."""
     if full.ndim < 2 or not full.is_contiguous():
         raise ValueError("allgather_rows needs a contiguous (B, N, ...) tensor")
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    if world == 1 and impl != "native":
-        return    # (an explicit "native" still goes through the communicator: that is how one GPU rehearses it)
+    if world == 1 and impl in (None, "auto"):
+        return
     B, N = full.shape[:2]
+    if full.numel() == 0:
+        return
     row_bytes = full[0, 0].numel() * full.element_size() if full.ndim > 2 else full.element_size()
     if _pick_impl(impl, full, group) == "native":
         from . import _rccl
 
-        comm = native_comm(group)
+        comm = native_comm(group, full.device)     # created (once) with the buffer's device current
         with torch.cuda.device(full.device):
             stream = ctypes.c_void_p(torch.cuda.current_stream(full.device).cuda_stream)
-            rc = _rccl.load().ps_allgather_rows(comm, ctypes.c_void_p(full.data_ptr()), B, N, row_bytes, stream)
+            rc = _rccl.load().ps_allgather_rows_ex(comm, ctypes.c_void_p(full.data_ptr()), B, N, row_bytes,
+                                                   _rccl.GATHER_FORCE_BROADCAST if force_broadcast else 0, stream)
         _rccl.check(rc, "ps_allgather_rows")
         return
-    _allgather_rows_torch(full.view(torch.uint8) if full.dtype == torch.bool else full, rank, world, group)
+    _allgather_rows_torch(full.view(torch.uint8) if full.dtype == torch.bool else full, rank, world, group,
+                          force_broadcast)
 
 
 def _coalescing(group, device):
@@ -128,10 +151,10 @@ def _coalescing(group, device):
     return contextlib.nullcontext()
 
 
-def _allgather_rows_torch(full: torch.Tensor, rank: int, world: int, group) -> None:
+def _allgather_rows_torch(full: torch.Tensor, rank: int, world: int, group, force_broadcast: bool = False) -> None:
     B, N = full.shape[:2]
     lo, hi = shard_rows(N, rank, world)
-    even = (N % world == 0)
+    even = (N % world == 0) and not force_broadcast
     in_place = even and dist.get_backend(group) == "nccl"
     with _coalescing(group, full.device):
         for b in range(B):

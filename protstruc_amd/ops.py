@@ -290,16 +290,21 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
     out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
     shape = (B, out_rows, N, A, A)
     mask_u8 = _u8c(atom_mask, "atom_mask")
+    _same_device(xyz, atom_mask=mask_u8)
+    # caller-supplied outputs are dereferenced by a kernel launched on xyz.device: a CPU tensor or a tensor of another
+    # GPU would be a wild device write, so device, shape, dtype and layout are all checked before anything is launched
+    for name, t, dt in (("out_dist", out_dist if want_dist else None, torch.float32),
+                        ("out_mask", out_mask if want_mask else None, torch.bool)):
+        if t is not None and (not isinstance(t, torch.Tensor) or t.device != xyz.device or tuple(t.shape) != shape
+                              or t.dtype != dt or not t.is_contiguous()):
+            raise ValueError(f"{name} must be a contiguous {str(dt).replace('torch.', '')} tensor of shape {shape} "
+                             f"on {xyz.device}")
     with _on(xyz.device):
         dist = dmask = None
         if want_dist:
             dist = out_dist if out_dist is not None else torch.empty(shape, dtype=torch.float32, device=xyz.device)
-            if dist.shape != shape or dist.dtype != torch.float32 or not dist.is_contiguous():
-                raise ValueError(f"out_dist must be a contiguous float32 tensor of shape {shape}")
         if want_mask:
             dmask = out_mask if out_mask is not None else torch.empty(shape, dtype=torch.bool, device=xyz.device)
-            if dmask.shape != shape or dmask.dtype != torch.bool or not dmask.is_contiguous():
-                raise ValueError(f"out_mask must be a contiguous bool tensor of shape {shape}")
         args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
         _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A, force=_autotune)
         cfg = _lib.k1_config(xyz.device)   # this device's settings, snapshotted for this launch

@@ -16,15 +16,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-# ---- multi-rank rehearsals ---------------------------------------------------------------------------------------
-# tools/rehearse_rowshard.py runs the row-sharded path with the real HIP kernels on 2 ranks (gloo, both on the one GPU
-# of the test box) and on 1 rank through RCCL.  A process that has initialised the GPU must not start other programs
-# on this pool, so the launchers are started HERE, at session start, before this pytest process has touched the GPU
-# (torch.cuda.device_count() does not initialise it); tests/test_gpu_multirank.py waits for their verdicts.
+# ---- multi-process rehearsals -------------------------------------------------------------------------------------
+# tools/gpu_session_rehearsals.py runs, as separate processes: the row-sharded path with the real HIP kernels on 2 ranks
+# (gloo, both on the one GPU of the test box) and on 1 rank through RCCL, the plain-C consumer of the C ABI, and -- once
+# those have ended, so that at most five processes use the card at any time -- ``python3 bench.py --gpus 2 --backend
+# gloo ...`` exactly as the driver invokes the bench for N > 1.  A process that has initialised the GPU must not start
+# other programs on this pool, so the orchestrator is started HERE, at session start, before this pytest process has
+# touched the GPU (torch.cuda.device_count() does not initialise it); the tests wait for the verdict files.
 REHEARSALS = {}
+_ORCHESTRATOR = None
 
 
 def pytest_sessionstart(session):
+    global _ORCHESTRATOR
     import subprocess
     import tempfile
 
@@ -37,26 +41,36 @@ def pytest_sessionstart(session):
     except Exception:  # noqa: BLE001
         return
     outdir = tempfile.mkdtemp(prefix="ps_rehearse_")
-    script = os.path.join(ROOT, "tools", "rehearse_rowshard.py")
-    for name, extra in (("gloo_world2", ["--world", "2", "--backend", "gloo"]),
-                        ("rccl_world1", ["--world", "1", "--backend", "nccl", "--quick"])):
-        out = os.path.join(outdir, name + ".json")
-        log = open(os.path.join(outdir, name + ".log"), "w")
-        proc = subprocess.Popen([sys.executable, script, "--out", out] + extra, stdout=log, stderr=subprocess.STDOUT)
-        REHEARSALS[name] = {"proc": proc, "out": out, "log": log.name}
-    # the plain-C consumer of the C ABI (examples/c_abi_demo.c): compiled with gcc and run as its own process
-    log = open(os.path.join(outdir, "c_abi_demo.log"), "w")
-    code = ("import sys, subprocess; sys.path.insert(0, %r); from protstruc_amd import build; "
-            "build.build(verbose=False); exe = build.build_c_example(verbose=False); "
-            "sys.exit(subprocess.run([exe]).returncode)" % ROOT)
-    proc = subprocess.Popen([sys.executable, "-c", code], stdout=log, stderr=subprocess.STDOUT)
-    REHEARSALS["c_abi_demo"] = {"proc": proc, "out": None, "log": log.name}
+    script = os.path.join(ROOT, "tools", "gpu_session_rehearsals.py")
+    log = open(os.path.join(outdir, "orchestrator.log"), "w")
+    _ORCHESTRATOR = subprocess.Popen([sys.executable, script, "--outdir", outdir], stdout=log, stderr=subprocess.STDOUT)
+    for name in ("gloo_world2", "rccl_world1", "c_abi_demo", "bench_gpus2"):
+        REHEARSALS[name] = {"exit": os.path.join(outdir, name + ".exit"), "out": os.path.join(outdir, name + ".json"),
+                            "log": os.path.join(outdir, name + ".log"), "stdout": os.path.join(outdir, name + ".stdout")}
+
+
+def wait_rehearsal(name, timeout):
+    """(exit code, log text) of a rehearsal, waiting up to ``timeout`` seconds for it to end."""
+    import time
+
+    if name not in REHEARSALS:
+        pytest.fail("the rehearsals were not started (conftest.pytest_sessionstart found no GPU?)")
+    r = REHEARSALS[name]
+    t_end = time.time() + timeout
+    while not os.path.exists(r["exit"]):
+        if time.time() > t_end or (_ORCHESTRATOR is not None and _ORCHESTRATOR.poll() is not None
+                                   and not os.path.exists(r["exit"])):
+            log = open(r["log"]).read()[-3000:] if os.path.exists(r["log"]) else "(no log)"
+            pytest.fail(f"rehearsal {name} did not finish in {timeout} s; log:\n{log}")
+        time.sleep(0.5)
+    with open(r["exit"]) as f:
+        code = int(f.read().strip())
+    return code, open(r["log"]).read()
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for r in REHEARSALS.values():
-        if r["proc"].poll() is None:
-            r["proc"].kill()      # exactly the launcher we started
+    if _ORCHESTRATOR is not None and _ORCHESTRATOR.poll() is None:
+        _ORCHESTRATOR.terminate()      # exactly the process we started (its children end with their own timeouts)
 
 
 def load_golden(name):

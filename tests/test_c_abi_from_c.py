@@ -18,15 +18,7 @@ def test_c99_consumer_compiles_and_links():
 
 @pytest.mark.gpu
 def test_c99_consumer_runs_on_the_gpu():
-    if "c_abi_demo" not in conftest.REHEARSALS:
-        pytest.fail("the C demo was not started (conftest.pytest_sessionstart found no GPU?)")
-    r = conftest.REHEARSALS["c_abi_demo"]
-    try:
-        code = r["proc"].wait(timeout=300)
-    except Exception:  # noqa: BLE001
-        r["proc"].kill()
-        pytest.fail("c_abi_demo did not finish; log:\n" + open(r["log"]).read()[-2000:])
-    log = open(r["log"]).read()
+    code, log = conftest.wait_rehearsal("c_abi_demo", 420)
     assert code == 0 and "c_abi_demo ok" in log, log[-2000:]
     assert "exact_sqrt=1" in log and "(0 one ulp off)" in log
     assert "hipGraph: 10 captured steps replayed twice, draw counter 20" in log

@@ -104,10 +104,16 @@ def test_native_shard_rows_matches_python():
     for n in (1, 7, 8, 229, 512, 2047, 2048, 2 ** 30):
         for world in (1, 2, 3, 4, 7, 8):
             for r in range(world):
-                lib.ps_shard_rows(n, r, world, ctypes.byref(lo), ctypes.byref(hi))
+                assert lib.ps_shard_rows(n, r, world, ctypes.byref(lo), ctypes.byref(hi)) == 0
                 assert (lo.value, hi.value) == shard_rows(n, r, world)
+    # precondition violations are an error code with lo = hi = 0, never a division by zero in the caller's process
+    for n, r, world in ((8, 0, 0), (8, 0, -1), (8, 2, 2), (8, -1, 2), (-1, 0, 1)):
+        lo.value = hi.value = 99
+        assert lib.ps_shard_rows(n, r, world, ctypes.byref(lo), ctypes.byref(hi)) == 1
+        assert (lo.value, hi.value) == (0, 0)
     # argument errors come back before any RCCL call
     assert lib.ps_allgather_rows(None, None, 1, 8, 64, None) == 1
+    assert lib.ps_allgather_rows_ex(None, None, 1, 8, 64, 0, None) == 1
     assert lib.ps_comm_create(None, None, 2, 0) == 1
     assert b"invalid" in lib.ps_comm_error_string(1).lower()
 

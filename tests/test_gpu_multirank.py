@@ -18,17 +18,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _verdict(name, timeout=420):
-    if name not in conftest.REHEARSALS:
-        pytest.fail("the rehearsal launchers were not started (conftest.pytest_sessionstart found no GPU?)")
-    r = conftest.REHEARSALS[name]
+    code, log = conftest.wait_rehearsal(name, timeout)
     try:
-        code = r["proc"].wait(timeout=timeout)
-    except Exception:  # noqa: BLE001
-        r["proc"].kill()
-        pytest.fail(f"rehearsal {name} did not finish in {timeout} s; log:\n" + open(r["log"]).read()[-3000:])
-    log = open(r["log"]).read()
-    try:
-        with open(r["out"]) as f:
+        with open(conftest.REHEARSALS[name]["out"]) as f:
             summary = json.load(f)
     except OSError:
         pytest.fail(f"rehearsal {name} wrote no verdict (exit {code}); log:\n{log[-3000:]}")
@@ -54,3 +46,31 @@ def test_one_rank_rccl_native_gather():
     assert code == 0 and s["ok"], (s["failed"], s["exit_codes"], log[-2000:])
     impls = {c.get("impl") for r in s["ranks"] for c in r["cases"] if c["op"] == "distance" and c["gather"] == "True"}
     assert impls == {"native", "torch"}
+    # the body of ps_allgather_rows_ex has executed on RCCL: grouped in-place ncclAllGather AND the per-(structure, owner)
+    # ncclBroadcast form, through the native library and through torch.distributed, bits intact
+    direct = {(c["impl"], c["force_broadcast"]) for r in s["ranks"] for c in r["cases"]
+              if c["op"] == "allgather_rows" and c["ok"]}
+    assert direct == {("native", False), ("native", True), ("torch", False), ("torch", True)}
+
+
+def test_bench_gpus2_self_launch_as_the_driver_invokes_it():
+    """``python3 bench.py --gpus 2 --backend gloo --steps 2 --warmup 1 --no-cpu-baseline`` with no launcher around it
+    (the command form the driver uses for N > 1): the parent starts two rank processes of itself, relays ONE JSON line
+    and exits 0; the headline check and the check after the gather are both ok and the strong-scaling keys are
+    top-level."""
+    code, log = conftest.wait_rehearsal("bench_gpus2", 900)
+    out = open(conftest.REHEARSALS["bench_gpus2"]["stdout"]).read()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    assert code == 0, (code, out[-500:], log[-3000:])
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak"
+    assert r["check"] == "ok" and r["rowshard_allgather"]["check_after_gather"] == "ok" and "rowshard_error" not in r
+    assert r["dist_backend"] == "gloo" and r["rccl_ranks"] == 0
+    assert r["roofline"]["kernel"].startswith("k1_pairdist_a15_pat") and r["roofline"]["kernel_family"] == "pattern"
+    assert r["roofline"]["buffer_fill_GBps"] > 0 and 0 < r["roofline"]["frac_of_buffer_fill"] < 2
+    for key in ("config4_kernel_only_pairs_per_s", "config4_kernel_only_efficiency_vs_1gpu",
+                "config4_allgather_ingress_GBps_per_rank", "config4_xgmi_ingress_bound_GBps_per_rank",
+                "config4_end_to_end_ms"):
+        assert isinstance(r[key], float) and r[key] > 0, key
+    assert len(r["per_rank_kernel_ms"]) == 2

@@ -446,6 +446,35 @@ def test_k1_capi_argument_validation_streams_and_capture(SB):
     assert torch.equal(gb[0], eb[0]) and torch.equal(gb[1], eb[1])
 
 
+def test_k1_caller_buffers_validated_before_launch(SB):
+    """Caller-supplied outputs (the path ``pairwise_distance_matrix_sharded(out_dist=, out_mask=)`` takes) and the atom
+    mask are dereferenced by a kernel on xyz's GPU: a CPU tensor, a wrong dtype / shape or a non-contiguous view must
+    raise before anything is launched, never become a wild device write."""
+    from protstruc_amd import ops
+    xyz, mask = synth(33, 2, 20)
+    xg, mg = xyz.cuda(), mask.cuda()
+    shape = (2, 20, 20, 15, 15)
+    good_d = torch.full(shape, 5.0, device="cuda")
+    good_m = torch.zeros(shape, dtype=torch.bool, device="cuda")
+    bad_outs = [
+        dict(out_dist=torch.empty(shape)),                                          # CPU distance buffer
+        dict(out_mask=torch.empty(shape, dtype=torch.bool)),                        # CPU mask buffer
+        dict(out_dist=torch.empty(shape, dtype=torch.float64, device="cuda")),      # wrong dtype
+        dict(out_mask=torch.empty(shape, dtype=torch.uint8, device="cuda")),
+        dict(out_dist=torch.empty((2, 20, 20, 15, 14), device="cuda")),             # wrong shape
+        dict(out_dist=torch.empty((2, 20, 20, 15, 30), device="cuda")[..., ::2]),   # right shape, strided
+    ]
+    for kw in bad_outs:
+        with pytest.raises(ValueError, match="must be a contiguous"):
+            ops.pairwise_distance(xg, mg, **{"out_dist": good_d, "out_mask": good_m, **kw})
+    with pytest.raises(RuntimeError, match="HIP-only"):
+        ops.pairwise_distance(xg, mask)                                             # CPU atom mask
+    torch.cuda.synchronize()
+    assert (good_d == 5.0).all() and not good_m.any()                               # nothing was launched
+    d, m = ops.pairwise_distance(xg, mg, out_dist=good_d, out_mask=good_m)
+    assert d is good_d and m is good_m and not torch.isnan(d).any()
+
+
 def test_k1_knobs_flipped_on_another_thread(SB):
     """The library holds no tuning state: every launch carries a snapshot of its device's host-side table.  One
     thread rewrites that table as fast as it can while two others launch K1 (pattern and flat-pattern shapes) on

@@ -82,6 +82,29 @@ def rank_main(args):
                             ok = same(a[:, lo:hi], want[:, lo:hi]) and bool((a[:, outside] == 77.0).all())
                         results.append({"op": f"angles{npts}", "B": B, "N": N, "gather": str(gather), "ok": bool(ok)})
                         ok_all &= bool(ok)
+        # The exchange itself, called directly with an EXPLICIT implementation (which issues the collectives at any world
+        # size, world 1 included -- a self-gather): on RCCL this is the body of ps_allgather_rows_ex, i.e.
+        # ncclGroupStart / in-place ncclAllGather per structure / ncclGroupEnd, and with force_broadcast the
+        # per-(structure, owner) in-place ncclBroadcast form that uneven splits take.  Rows owned by other ranks are
+        # poisoned first, so a gather that does not deliver them cannot pass.
+        for (B, N, A) in ((3, 48, 15), (2, 51, 5)):
+            g = torch.Generator().manual_seed(2000 + N)
+            xyz = torch.randn(B, N, A, 3, generator=g).to(dev)
+            mask = (torch.rand(B, N, A, generator=g) < 0.85).to(dev)
+            ref_d, ref_m = ops.pairwise_distance(xyz, mask)
+            lo, hi = D.shard_rows(N, args.rank, args.world)
+            for impl in (("native", "torch") if args.backend == "nccl" else ("torch",)):
+                for fb in (False, True):
+                    d, m = ref_d.clone(), ref_m.clone()
+                    d[:, :lo] = -3.0; d[:, hi:] = -3.0
+                    m[:, :lo] = False; m[:, hi:] = False
+                    D.allgather_rows(d, impl=impl, force_broadcast=fb)
+                    D.allgather_rows(m, impl=impl, force_broadcast=fb)
+                    torch.cuda.synchronize(dev)
+                    ok = same(d, ref_d) and torch.equal(m, ref_m)
+                    results.append({"op": "allgather_rows", "B": B, "N": N, "A": A, "impl": impl,
+                                    "force_broadcast": fb, "gather": "True", "ok": bool(ok)})
+                    ok_all &= bool(ok)
         # the same through the StructureBatch methods
         from protstruc_amd import StructureBatch
         g = torch.Generator().manual_seed(77)
