@@ -70,6 +70,9 @@ typedef struct ps_k1_config {
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int anya_fl_log2;     /* any-A flat kernel: log2(pairs per chunk), 0 = auto */
+    int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
+    int small_a;          /* atom counts 1..13 other than 4, 8: 0 (default) the row-phase kernel; 1 the round-2 paths (odd
+                             row-tile kernels + k1_mask_rows for A = 3, 5; flat / any-A / element kernels otherwise) */
     int experiment;       /* must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
                              run that writes WRONG values, +16 = fully unrolled group loop */

@@ -474,8 +474,9 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
 //     bookkeeping at all;
 //   * [pbeg, pend) need not be 16-pair aligned (odd N; one structure of a row-sharded launch): partially active
 //     groups take the element-wise path and inactive pairs are never written.
-constexpr int FL = 128;  // pairs per chunk
-constexpr int FR = 16;   // row residues staged per chunk (N >= 16 -> a chunk touches at most 9 rows)
+// FLOG2: log2(pairs per chunk).  7 (128 pairs = 144 KB of output per chunk) is the product default; 4..6 are the
+// small-granule variants of round 3's bounded A/B (cfg.flat_fl_log2; profiles/r03_k1_ab_small_granule.log).
+constexpr int FR = 16;   // row residues staged per chunk (N >= 16 -> a chunk of up to 128 pairs touches at most 9 rows)
 
 // floor(x / d) for x, d < 2^23 with rcp = 1.0f / d
 __device__ __forceinline__ unsigned udiv_rcp(unsigned x, unsigned d, float rcp) {
@@ -486,7 +487,7 @@ __device__ __forceinline__ unsigned udiv_rcp(unsigned x, unsigned d, float rcp) 
     return q;
 }
 
-template <bool EXACT, bool HASMASK>
+template <bool EXACT, bool HASMASK, int FLOG2>
 __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __restrict__ xyz,
                                                             const uint8_t* __restrict__ amask,
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                                                             unsigned pbeg, unsigned pend, unsigned n_ranges,
                                                             unsigned range_stride, unsigned cpr, int cpw,
                                                             int xcd_remap, double rcpN_d, double rcpR_d) {
+    constexpr int FL = 1 << FLOG2;
     __shared__ __attribute__((aligned(16))) float4 sxj[FL * RS];
     __shared__ __attribute__((aligned(16))) float4 sxi[FR * RS];
     __shared__ uint32_t smj[FL], smi[FR], smc[FL];
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
             k = chunk - rg * cpr;
         }
         const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
-        const unsigned P0 = ((rbeg >> 7) + k) << 7;
+        const unsigned P0 = ((rbeg >> FLOG2) + k) << FLOG2;
         if (P0 >= rend) continue;  // uniform: cpr is an upper bound when ranges start at different phases
         const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
         const int hi = rend - P0 < (unsigned)FL ? (int)(rend - P0) : FL;
@@ -1611,6 +1613,180 @@ __global__ __launch_bounds__(256) void k1_mask_rows(const uint8_t* __restrict__ 
     }
 }
 
+// ---- row-phase kernel: small atom counts, ANY length (A <= 13 without a multiple-of-4 count; A = 1, 2 included) ----
+// The column-stationary idea of the row-tile kernels without their alignment conditions.  A row run of the distance plane
+// starts (R * N * A*A) mod 4 floats past a 16-byte boundary (R = absolute row of the buffer); for even A that is always 0,
+// for odd A it is one of four PHASES fixed by R mod 4.  Slots are cut on the ABSOLUTE 16-byte grid: slot s of a row with
+// phase ph holds row elements 4 s - ph .. 4 s - ph + 3.  A lane owns slot s (two of them, 256 apart) of every row of its
+// workgroup, keeps the column atoms of the SEVEN elements 4 s - 3 .. 4 s + 3 in registers (four when there is one phase
+// only), and -- the phase being uniform over the workgroup -- takes one of four straight-line arms per row that uses the
+// window 3 - ph .. 6 - ph of them.  So, unlike the phased variant of the odd row-tile kernel this replaces (rows of one
+// residue class of R mod 4 per workgroup, three launches' worth of strided row streams in flight), a workgroup writes IR
+// CONSECUTIVE rows: one sequential stream per workgroup, as in the aligned kernels.
+//   * tiles are cut in slot space, so a slot never belongs to two tiles; the only shared slots are the one that holds a
+//     row's end and the next row's start, which both rows write element-wise (their own elements only);
+//   * the mask plane rides in the same loop: the four mask bytes of a slot's elements are one aligned dword store (byte
+//     offset = float offset of the slot), so it needs neither a 16-byte phase of its own nor a second launch;
+//   * the four row atoms of a slot's elements are LDS reads (broadcasts: many lanes read the same few atoms); for A = 1
+//     there is a single row atom, read once per row.
+template <int A>
+struct RowPhase {
+    static_assert(A >= 1 && A <= 13, "row-phase kernel: small atom counts");
+    static constexpr int AA = A * A;
+    static constexpr bool PHASED = (AA % 4) != 0;      // odd A (A*A = 1 mod 4); even A: every row run is 16-byte aligned
+    static constexpr int W = PHASED ? 7 : 4;           // elements per slot whose column atoms a lane keeps
+    static constexpr int W0 = PHASED ? 3 : 0;          // window element of row element 4 s
+    static constexpr int SPL = 2;                      // slots per lane per row
+    static constexpr int TS = 256 * SPL;               // slots per tile-row at most (8 KB of distances)
+    static constexpr int MAXRES = (4 * TS + 2) / AA + 2;   // column residues a tile's elements can touch
+};
+
+template <int A, bool EXACT, int PH>
+__device__ __forceinline__ void rowphase_row(const float4* __restrict__ sxi_row, uint32_t mi, const float (&col)[7][3],
+                                             uint32_t aw, uint32_t cm, uint32_t valid, float* __restrict__ od,
+                                             uint8_t* __restrict__ om) {
+    // one slot of one row: od / om point at the slot (float / byte offset 4 s - ph of the row run), PH = the row's phase
+    using T = RowPhase<A>;
+    constexpr int WO = T::W0 - PH;                     // window element of the slot's first element
+    const uint32_t vm = (valid >> WO) & 15u;
+    if (vm == 0u) return;
+    float v[4];
+    uint32_t rowbits = 0;
+    float4 xi0;
+    if (A == 1) xi0 = sxi_row[0];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t a = (A == 1) ? 0u : ((aw >> (4 * (WO + k))) & 15u);
+        const float4 xi = (A == 1) ? xi0 : sxi_row[a];
+        v[k] = dist_pp<EXACT>(xi, make_float4(col[WO + k][0], col[WO + k][1], col[WO + k][2], 0.f));
+        rowbits |= ((mi >> a) & 1u) << k;
+    }
+    const uint32_t m4 = rowbits & (cm >> WO) & 15u;
+    if (vm == 15u) {
+        if (od) store16<false>(od, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                              __float_as_uint(v[3])));
+        if (om) *reinterpret_cast<uint32_t*>(om) = spread4(m4);
+    } else {   // the slot that holds a row's start or end: this row's elements only
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((vm >> k) & 1u) {
+                if (od) od[k] = v[k];
+                if (om) om[k] = (uint8_t)((m4 >> k) & 1u);
+            }
+    }
+}
+
+template <int A, bool EXACT>
+__global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restrict__ xyz,
+                                                            const uint8_t* __restrict__ amask,
+                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
+                                                            int N, int row_begin, int row_end, int out_rows,
+                                                            int out_row_origin, int IR, int n_tiles, int spt,
+                                                            int n_ichunks, int xcd_remap) {
+    using T = RowPhase<A>;
+    constexpr int AA = T::AA, W = T::W;
+    extern __shared__ __attribute__((aligned(16))) char smem_rp[];
+    float4* sxi = reinterpret_cast<float4*>(smem_rp);                   // [IR * A] row atoms
+    uint32_t* smi = reinterpret_cast<uint32_t*>(sxi + IR * A);          // [IR] row mask bits
+    uint32_t* smj = smi + IR;                                           // [MAXRES] column mask bits
+    float* sxj = reinterpret_cast<float*>(smj + T::MAXRES);             // [MAXRES * A * 3] column coordinates, as in HBM
+
+    const int tid = threadIdx.x;
+    unsigned w = blockIdx.x;
+    if (xcd_remap) {
+        const unsigned n = gridDim.x, x = w & 7u;
+        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
+    }
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_ichunks);
+    const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
+    const int in = min(IR, row_end - i0);
+    const int nel = N * AA;                                             // elements of one row run
+    const int nslots = T::PHASED ? (nel + 6) / 4 : nel / 4;            // slots a row can touch, over all phases
+    const int s0 = (int)tile * spt, s1 = min(s0 + spt, nslots);
+    // column residues the tile's elements 4 s0 - 3 .. 4 s1 - 1 belong to
+    const int t_lo = max(4 * s0 - T::W0, 0), t_hi = min(4 * s1 - 1, nel - 1);
+    const int j_lo = t_lo / AA, j_hi = t_hi / AA, nres = j_hi - j_lo + 1;
+
+    {   // stage: the tile's column residues are one contiguous float range of xyz; row atoms one float4 each
+        const float* gj = xyz + ((size_t)b * N + j_lo) * (A * 3);
+        for (int f = tid; f < nres * (A * 3); f += 256) sxj[f] = gj[f];
+        const float* gi = xyz + ((size_t)b * N + i0) * (A * 3);
+        float* li = reinterpret_cast<float*>(sxi);
+        for (int f = tid; f < in * (A * 3); f += 256) {
+            const int atom = f / 3, comp = f - atom * 3;
+            li[atom * 4 + comp] = gi[f];
+        }
+        for (int r = tid; r < nres + in; r += 256) {
+            const bool is_j = r < nres;
+            const int rl = is_j ? r : r - nres;
+            uint32_t bits = (1u << A) - 1u;
+            if (amask) {
+                const uint8_t* m = amask + ((size_t)b * N + (is_j ? j_lo : i0) + rl) * A;
+                bits = 0;
+#pragma unroll
+                for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+            }
+            (is_j ? smj : smi)[rl] = bits;
+        }
+    }
+    __syncthreads();
+
+    // per-lane pattern: column atom, row-atom index, column mask bit and validity of every window element
+    float col[T::SPL][7][3];
+    uint32_t aw[T::SPL], cm[T::SPL], valid[T::SPL];
+#pragma unroll
+    for (int u = 0; u < T::SPL; ++u) {
+        const int s = s0 + 256 * u + tid;
+        aw[u] = cm[u] = valid[u] = 0;
+#pragma unroll
+        for (int wi = 0; wi < 7; ++wi) {
+            col[u][wi][0] = col[u][wi][1] = col[u][wi][2] = 0.f;
+            if (wi < W) {
+                const int t = 4 * s - T::W0 + wi;
+                const bool ok = s < s1 && t >= 0 && t < nel;
+                const unsigned e = ok ? (unsigned)t : (unsigned)t_lo;
+                const unsigned j = e / AA, r = e - j * AA;
+                const unsigned a = r / A, c = r - a * A;
+                const float* p = sxj + ((j - (unsigned)j_lo) * A + c) * 3;
+                col[u][wi][0] = p[0];
+                col[u][wi][1] = p[1];
+                col[u][wi][2] = p[2];
+                aw[u] |= a << (4 * wi);
+                cm[u] |= (ok ? ((smj[j - (unsigned)j_lo] >> c) & 1u) : 0u) << wi;
+                valid[u] |= (ok ? 1u : 0u) << wi;
+            }
+        }
+    }
+
+    const long long Rb = (long long)b * out_rows - out_row_origin;    // absolute row of the buffer = Rb + i
+    const unsigned nel4 = (unsigned)nel & 3u;
+#pragma unroll 1
+    for (int il = 0; il < in; ++il) {
+        const long long R = Rb + i0 + il;
+        const unsigned ph = T::PHASED ? (((unsigned)(R & 3) * nel4) & 3u) : 0u;    // (R * nel) mod 4: uniform
+        const size_t rowoff = (size_t)R * (size_t)nel;
+        const float4* xi = sxi + il * A;
+        const uint32_t mi = smi[il];
+#pragma unroll
+        for (int u = 0; u < T::SPL; ++u) {
+            const long long eo = 4ll * (s0 + 256 * u + tid) - (long long)ph;   // row element of the slot's first float
+            float* od = dist ? dist + rowoff + eo : nullptr;
+            uint8_t* om = dmask ? dmask + rowoff + eo : nullptr;
+            if constexpr (!T::PHASED) {
+                rowphase_row<A, EXACT, 0>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om);
+            } else {
+                switch (ph) {   // uniform over the workgroup
+                    case 0: rowphase_row<A, EXACT, 0>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
+                    case 1: rowphase_row<A, EXACT, 1>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
+                    case 2: rowphase_row<A, EXACT, 2>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
+                    default: rowphase_row<A, EXACT, 3>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
+                }
+            }
+        }
+    }
+}
+
 // ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
 // Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
 // fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
@@ -1961,8 +2137,10 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
                     int N, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
                     unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
-    // chunks per range: exact for one range, an upper bound when the ranges start at different 128-pair phases
-    const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> 7) - (pbeg >> 7) : ((pend - pbeg) >> 7) + 2;
+    // chunks per range: exact for one range, an upper bound when the ranges start at different chunk phases
+    const int L2 = g.flat_fl_log2 ? g.flat_fl_log2 : 7;
+    const unsigned FL = 1u << L2;
+    const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     // like rows_per_block this depends on the output allocation: four chunks per workgroup are 1-2 % faster on some
@@ -1972,13 +2150,17 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
     const size_t pad = (size_t)g.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap
+#define PS_K1_FLAT2(EX_, HM_, L_)                                                                                 \
+    k1_go(go, "flat", "k1_pairdist_a15_flat", 1 << L_, k1_pairdist_a15_flat<EX_, HM_, L_>, dim3(n_wg), dim3(256), pad, \
+          xyz, amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr,       \
+          (int)cpw, remap, rn, rr)
 #define PS_K1_FLAT(EX_, HM_)                                                                                      \
-    k1_go(go, "flat", "k1_pairdist_a15_flat", -1, k1_pairdist_a15_flat<EX_, HM_>, dim3(n_wg), dim3(256), pad, xyz, \
-          amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw,  \
-          remap, rn, rr)
+    (L2 == 7 ? PS_K1_FLAT2(EX_, HM_, 7) : L2 == 6 ? PS_K1_FLAT2(EX_, HM_, 6) : L2 == 5 ? PS_K1_FLAT2(EX_, HM_, 5)  \
+                                                                              : PS_K1_FLAT2(EX_, HM_, 4))
     if (g.exact_sqrt) return amask ? PS_K1_FLAT(true, true) : PS_K1_FLAT(true, false);
     return amask ? PS_K1_FLAT(false, true) : PS_K1_FLAT(false, false);
 #undef PS_K1_FLAT
+#undef PS_K1_FLAT2
 }
 
 // Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37,
@@ -2000,6 +2182,7 @@ bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmas
     // plane goes through k1_mask_rows.  Any other N: the distance rows are taken in four phase classes (PHASED) and the
     // mask plane again goes through k1_mask_rows, whose LDS image holds all N column masks.
     if ((A != 3 && A != 5) || N < 1 || N > 8192) return false;
+    if (g.small_a != 1) return false;   // since round 3 the row-phase kernel is the default for A = 3, 5; this is the A/B path
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
@@ -2068,6 +2251,41 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
     return k1_go(go, "rowtile", "k1_pairdist_rowtile", A, k1_pairdist_rowtile<A, false>, dim3((unsigned)n_wg), dim3(256),
                  lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks,
                  remap);
+}
+
+// Row-phase kernel: the small atom counts that have no multiple-of-4 row-tile kernel, any N, any row range.
+bool rowphase_has(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
+
+bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
+    if (g.variant != 0 || g.flat != 1 || g.small_a != 0 || !rowphase_has(A)) return false;
+    if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
+    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
+template <int A>
+int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
+                    int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
+    using T = RowPhase<A>;
+    const int rows = row_end - row_begin;
+    const int n_ichunks = (rows + 31) / 32, IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 rows, balanced
+    const int nel = N * T::AA;
+    const int nslots = T::PHASED ? (nel + 6) / 4 : nel / 4;
+    const int n_tiles = (nslots + T::TS - 1) / T::TS;
+    int spt = (nslots + n_tiles - 1) / n_tiles;          // slots per tile-row, balanced over the tiles, whole waves
+    spt = ((spt + 63) / 64) * 64;
+    if (spt > T::TS) spt = T::TS;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * ((rows + IR - 1) / IR) * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
+    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)IR * 4 + (size_t)T::MAXRES * 4 +
+                       (size_t)T::MAXRES * A * 3 * sizeof(float);
+    if (g.exact_sqrt)
+        return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, true>, dim3((unsigned)n_wg),
+                     dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR,
+                     n_tiles, spt, (rows + IR - 1) / IR, remap);
+    return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, false>, dim3((unsigned)n_wg),
+                 dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles,
+                 spt, (rows + IR - 1) / IR, remap);
 }
 
 bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
@@ -2167,6 +2385,8 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
     if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
     if (g.anya_fl_log2 != 0 && (g.anya_fl_log2 < 4 || g.anya_fl_log2 > 10)) return false;
+    if (g.small_a < 0 || g.small_a > 1) return false;
+    if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
 #ifdef PS_EXPERIMENTS
     if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
 #else
@@ -2212,6 +2432,15 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
             return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
         return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
     }
+    if (rowphase_eligible(g, dist, dist_mask, N, A)) {
+#define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
+        switch (A) {
+            PS_K1_RP(1) PS_K1_RP(2) PS_K1_RP(3) PS_K1_RP(5) PS_K1_RP(6) PS_K1_RP(7) PS_K1_RP(9) PS_K1_RP(10) PS_K1_RP(11)
+            PS_K1_RP(12) PS_K1_RP(13)
+            default: break;
+        }
+#undef PS_K1_RP
+    }
     if (rowtile_odd_eligible(g, dist, dist_mask, N, A)) {
         if (A == 3)
             return launch_rowtile_odd<3>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
@@ -2256,6 +2485,8 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
     // the flat kernels above and the pattern kernel run on 1-D grids and take any batch size; the slot-decode and the
     // element-per-lane kernels put the structure on grid.z (checked where they are launched)
     if (A == A15) {
+        // N < 16 (peptides): a row run is at most 13.5 KB, so the slot-decode kernel takes up to 16 rows per workgroup
+        if (N < 16 && g.rows_per_block == 1) g.rows_per_block = rows < 16 ? rows : 16;
         if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
         const int jt = g.jt ? g.jt : (N >= 256 ? 128 : 64);
         if (jt == 128)

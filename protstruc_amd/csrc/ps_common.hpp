@@ -120,18 +120,47 @@ __device__ __forceinline__ float atan2_ps(float y, float x) {
     return copysignf(r, y);
 }
 
-// geometry.dihedral (geometry.py:108-124)
+// acos for the planar-angle kernels: acos(|x|) = sqrt(1 - |x|) * P(|x|) with the degree-7 polynomial of Abramowitz &
+// Stegun 4.4.46 (|error| <= 2e-8 in exact arithmetic; 4.3e-7 absolute = 1 ulp of pi in fp32, checked over 4.2e6 points
+// incl. 1e-12 from +-1 -- the same size as the library routine's), reflected for negative arguments.  |x| > 1 gives NaN
+// through the square root of a negative number, as acos without a clamp does in the reference (geometry.py:64-71); NaN
+// propagates.  14 instructions instead of the library's ~40: K3's planar-angle path is VALU-issue bound.
+__device__ __forceinline__ float acos_ps(float x) {
+    const float ax = fabsf(x);
+    float p = -0.0012624911f;
+    p = __builtin_fmaf(p, ax, 0.0066700901f);
+    p = __builtin_fmaf(p, ax, -0.0170881256f);
+    p = __builtin_fmaf(p, ax, 0.0308918810f);
+    p = __builtin_fmaf(p, ax, -0.0501743046f);
+    p = __builtin_fmaf(p, ax, 0.0889789874f);
+    p = __builtin_fmaf(p, ax, -0.2145988016f);
+    p = __builtin_fmaf(p, ax, 1.5707963050f);
+    const float r = p * __builtin_amdgcn_sqrtf(1.0f - ax);
+    return (__float_as_uint(x) >> 31) ? (3.141592653589793f - r) : r;
+}
+
+// geometry.dihedral (geometry.py:108-124), with the 1e-5 parity tolerance spent on ONE algebraic step (round 3):
+//   reference:  n1 = b0 x b1,  n2 = b2 x b1,  x = n1 . n2,  y = ((n1 x n2) . b1) / |b1|
+//   here:       n1, n2, x bit for bit as the reference;  (n1 x n2) = -(n1 . b2) b1 exactly in real arithmetic, so
+//               y = -(n1 . b2) |b1| and, atan2 being invariant under a common positive factor,
+//               atan2(y, x) = atan2(n1 . (c - d), x / |b1|):
+// one cross product (9 of ~47 flops) fewer and no square root, only v_rsq_f32.  What must stay EXACT stays exact:
+//   * c - d is the exact negative of the reference's b2 = d - c, and n2 = b1 x (c - d) has the reference's two products
+//     per component and their difference, i.e. the same bits as b2 x b1;
+//   * on the diagonal of pairwise_dihedrals (i == j) n1 or n2 is exactly 0, both dot products start from +0 (dot3), so
+//     y = +0 and x = +0 * rsq = +0 and the result is +0.0 with no sign bit, as in the reference (golden G3);
+//   * b1 = 0 gives x = 0 * inf = NaN like the reference's 0 / 0; NaN coordinates propagate.
+// Everywhere else the result differs from the reference's by rounding only (max 2.4e-7 off-diagonal at unit scale
+// before and after, tools/k3_error_stats.py; the conditioning gates of tests/test_gpu_parity.py hold it to the oracle
+// and to fp64).
 __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
     f3 b0 = sub3(a, b);
     f3 b1 = sub3(c, b);
-    f3 b2 = sub3(d, c);
+    f3 b2n = sub3(c, d);
     f3 n1 = cross3(b0, b1);
-    f3 n2 = cross3(b2, b1);
-    f3 m = cross3(n1, n2);
-    float x = dot3(n1, n2);
-    // y = (m . b1) / |b1| as in the reference, evaluated as (m . b1) * rsq(b1 . b1): one v_rsq_f32 (1 ulp) instead of
-    // a correctly rounded sqrt plus an IEEE divide (19 instructions); b1 = 0 still gives 0 * inf = NaN like 0 / 0.
-    float y = dot3(m, b1) * __builtin_amdgcn_rsqf(dot3(b1, b1));
+    f3 n2 = cross3(b1, b2n);
+    float x = dot3(n1, n2) * __builtin_amdgcn_rsqf(dot3(b1, b1));
+    float y = dot3(n1, b2n);
     return atan2_ps(y, x);
 }
 
@@ -193,11 +222,30 @@ __device__ __forceinline__ f32x2 atan2_ps_v(f32x2 y, f32x2 x) {
 }
 
 __device__ __forceinline__ f32x2 dihedral4v(f3v a, f3v b, f3v c, f3v d) {
-    const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2 = sub3v(d, c);
-    const f3v n1 = cross3v(b0, b1), n2 = cross3v(b2, b1), m = cross3v(n1, n2);
-    const f32x2 x = dot3v(n1, n2), ym = dot3v(m, b1), nn = dot3v(b1, b1);
-    const f32x2 yv = ym * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
-    return atan2_ps_v(yv, x);
+    const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2n = sub3v(c, d);
+    const f3v n1 = cross3v(b0, b1), n2 = cross3v(b1, b2n);
+    const f32x2 nn = dot3v(b1, b1);
+    const f32x2 x = dot3v(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+    const f32x2 y = dot3v(n1, b2n);
+    return atan2_ps_v(y, x);
+}
+
+// acos_ps on both halves (same operations in the same order per element)
+__device__ __forceinline__ f32x2 acos_ps_v(f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 p = k2(-0.0012624911f);
+    p = __builtin_elementwise_fma(p, ax, k2(0.0066700901f));
+    p = __builtin_elementwise_fma(p, ax, k2(-0.0170881256f));
+    p = __builtin_elementwise_fma(p, ax, k2(0.0308918810f));
+    p = __builtin_elementwise_fma(p, ax, k2(-0.0501743046f));
+    p = __builtin_elementwise_fma(p, ax, k2(0.0889789874f));
+    p = __builtin_elementwise_fma(p, ax, k2(-0.2145988016f));
+    p = __builtin_elementwise_fma(p, ax, k2(1.5707963050f));
+    const f32x2 t = k2(1.0f) - ax;
+    const f32x2 r = p * f32x2{__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+    const f32x2 rh = k2(3.141592653589793f) - r;
+    return f32x2{(__float_as_uint(x.x) >> 31) ? rh.x : r.x, (__float_as_uint(x.y) >> 31) ? rh.y : r.y};
 }
 
 // sqrt_rn_mk on both halves: v_rsq_f32 and the class test per element, the Newton / residual steps as packed fma
@@ -221,19 +269,23 @@ __device__ __forceinline__ f32x2 dist3v(f3v a, f3v b) {
     return sqrt_rn_mk_v((sx + sy) + sz);
 }
 
+// geometry.angle (geometry.py:64-71): no clamp before acos.  The reference divides the dot product by the product of
+// two norms; here cos = (ba . bc) * rsq((ba . ba) * (bc . bc)) -- one v_rsq_f32 (1 ulp) instead of two correctly rounded
+// square roots and an IEEE divide (3 instructions instead of ~29; the relative rounding error of the cosine is ~1.5 ulp
+// either way) -- and acos_ps above.  A zero-length arm (the diagonal of pairwise_planar_angles) is 0 * rsq(0) = 0 * inf
+// = NaN like the reference's 0 / 0; the squared lengths multiply without overflow up to 1e9 A arms.
 __device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
     const f3v ba = sub3v(a, b), bc = sub3v(c, b);
     const f32x2 num = dot3v(ba, bc);
-    const f32x2 den = sqrt_rn_mk_v(dot3v(ba, ba)) * sqrt_rn_mk_v(dot3v(bc, bc));
-    return f32x2{acosf(num.x / den.x), acosf(num.y / den.y)};
+    const f32x2 q = dot3v(ba, ba) * dot3v(bc, bc);
+    return acos_ps_v(num * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)});
 }
 
-// geometry.angle (geometry.py:64-71): no clamp before acos
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     f3 ba = sub3(a, b);
     f3 bc = sub3(c, b);
-    float cosine = dot3(ba, bc) / (norm3(ba) * norm3(bc));
-    return acosf(cosine);
+    const float q = dot3(ba, ba) * dot3(bc, bc);
+    return acos_ps(dot3(ba, bc) * __builtin_amdgcn_rsqf(q));
 }
 
 // geometry.gram_schmidt (geometry.py:428-439); e3 uses the last-axis cross

@@ -59,16 +59,18 @@ def test_k1_golden(SB, name):
     assert torch.equal(m.cpu(), g["dist_mask"])
 
 
-@pytest.mark.parametrize("A", [14, 37, 25, 3, 4, 5, 8, 16])
-def test_k1_golden_other_atom_counts(SB, A):
-    """G13: the reference itself at the atom counts that take the fixed-A flat pattern kernels (N >= 16): sampled whole
-    (b,i,j) blocks within 1e-5 with NaN positions exact, mask blocks and every pair's mask count exact, per-pair
-    distance sums.  (`from_xyz` accepts any atom count: reference protstruc.py:94-128, tests/test_StructureBatch.py:11-21.)"""
-    g = load_golden("g13_dist_atom_counts")
-    t = f"a{A}"
+@pytest.mark.parametrize("fixture,t", [("g13_dist_atom_counts", f"a{A}") for A in (14, 37, 25, 3, 4, 5, 8, 16)] +
+                         [("g14_dist_small_atom_counts", t) for t in ("a1", "a2", "a6", "a7", "a10", "a13", "a1n7", "a9")])
+def test_k1_golden_other_atom_counts(SB, fixture, t):
+    """G13 / G14: the reference itself at the atom counts that take the fixed-A flat pattern, row-tile and row-phase
+    kernels (G14: single atoms = CA traces, atom pairs, 6 / 7 / 9 / 10 / 13 atoms, lengths of every alignment phase and
+    below 16): sampled whole (b,i,j) blocks within 1e-5 with NaN positions exact, mask blocks and every pair's mask
+    count exact, per-pair distance sums.  (`from_xyz` accepts any atom count: reference protstruc.py:94-128,
+    tests/test_StructureBatch.py:11-21.)"""
+    g = load_golden(fixture)
     sb = SB.from_xyz(g[f"{t}_xyz"], g[f"{t}_atom_mask"])
     d, m = sb.pairwise_distance_matrix()
-    assert m.dtype == torch.bool and d.shape[-1] == A
+    assert m.dtype == torch.bool and d.shape[-1] == g[f"{t}_xyz"].shape[2]
     b, i, j = g[f"{t}_b"].long().cuda(), g[f"{t}_i"].long().cuda(), g[f"{t}_j"].long().cuda()
     assert_close(d[b, i, j], g[f"{t}_dist_blocks"])
     assert torch.equal(m[b, i, j].cpu(), g[f"{t}_mask_blocks"])
@@ -251,12 +253,13 @@ def _same_floats(a, b):
 
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
-    """The vectorised any-A flat kernel (k1_flat=3), the fixed-A flat pattern kernels (k1_flat=4) and the row-tile
-    kernel of A = 4 / 8 (k1_flat=1, the default dispatch)
+    """The vectorised any-A flat kernel (k1_flat=3), the fixed-A flat pattern kernels (k1_flat=4), the row-tile kernels
+    of A = 4 / 8 and the row-phase kernel of the other small atom counts (k1_flat=1, the default dispatch), and the
+    round-2 odd row-tile paths (k1_small_a=1)
     against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
     at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt", "k1_small_a")
     saved = {k: _lib.get_tuning(k) for k in keys}
     _lib.set_tuning("k1_exact_sqrt", exact)
     SENT = 12345.0
@@ -275,10 +278,29 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              # N % 4 == 0 but not % 16: distances by the odd row-tile kernel, mask plane by k1_mask_rows
              (2, 20, 5), (3, 100, 5), (2, 500, 5), (2, 36, 3), (1, 228, 3), (3, 44, 3),
              # any other N: distance rows in four alignment-phase classes (odd N, N % 4 == 2, tiny N)
-             (2, 17, 5), (3, 101, 5), (2, 499, 5), (2, 30, 5), (2, 19, 3), (1, 229, 3), (2, 6, 3), (2, 3, 5), (4, 2, 5)]
+             (2, 17, 5), (3, 101, 5), (2, 499, 5), (2, 30, 5), (2, 19, 3), (1, 229, 3), (2, 6, 3), (2, 3, 5), (4, 2, 5),
+             # row-phase kernel (round 3; A = 1, 2, 3, 5, 6, 7, 9..13): single atoms and pairs of atoms, every phase of
+             # odd A, several tiles per row (A = 1: N > 2042; A = 5: N > 81; A = 13: N > 12), more rows than one
+             # workgroup takes (N > 32), tiny N
+             (2, 500, 1), (2, 501, 1), (2, 502, 1), (2, 503, 1), (1, 2100, 1), (3, 5, 1), (2, 1, 1), (1, 1030, 2),
+             (2, 2, 2), (2, 99, 2), (2, 100, 6), (2, 37, 7), (2, 3, 7), (1, 64, 9), (2, 50, 10), (2, 33, 11), (1, 40, 12),
+             (2, 29, 13), (1, 90, 5), (1, 91, 5), (1, 93, 3), (1, 94, 3)]
+
+    def paths(A):
+        """(k1_flat, k1_small_a) settings that reach a fast kernel for this atom count."""
+        if A in (4, 8):
+            return [(1, 0), (3, 0), (4, 0)]
+        if A in (3, 5):
+            return [(1, 0), (1, 1), (3, 0) if A == 5 else (4, 0), (4, 0)]
+        if A in (1, 2):
+            return [(1, 0)]
+        if A in (14, 15, 16, 25, 37):
+            return [(3, 0), (4, 0)]
+        return [(1, 0), (3, 0)] if A <= 13 else [(3, 0)]
+
     try:
-        for (B, N, A), flat in [(c, f) for c in cases
-                             for f in ((1, 3, 4) if c[2] in (3, 4, 5, 8) else (3, 4) if c[2] in (14, 15, 16, 25, 37) else (3,))]:
+        for (B, N, A), (flat, small_a) in [(c, f) for c in cases for f in paths(c[2])]:
+            _lib.set_tuning("k1_small_a", small_a)
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
@@ -299,8 +321,8 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
                 d = bd[pad:pad + numel].view(ref_d.shape)
                 m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
                 ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
-                assert _same_floats(d, ref_d), (B, N, A, cpw, flat)
-                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat)
+                assert _same_floats(d, ref_d), (B, N, A, cpw, flat, small_a)
+                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat, small_a)
                 assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
                 assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
                 d0, _ = ops.pairwise_distance(xg, None, want_mask=False)
@@ -308,6 +330,8 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
                 _, m1 = ops.pairwise_distance(xg, mg, want_dist=False)
                 assert torch.equal(m1, ref_m)
                 for r0, r1 in [(0, 1), (1, N - 1), (N // 2, N)]:
+                    if r0 >= r1:
+                        continue
                     cd, cm = ops.pairwise_distance(xg, mg, row_begin=r0, row_end=r1, compact=True)
                     assert _same_floats(cd, ref_d[:, r0:r1].contiguous()) and torch.equal(cm, ref_m[:, r0:r1])
                     fd = torch.full_like(ref_d, SENT)

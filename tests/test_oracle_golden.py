@@ -204,15 +204,16 @@ def test_align_topk_select():
     assert torch.equal(xyz[:1][g["pick"]].unsqueeze(0), g["picked_xyz"])
 
 
-ATOM_COUNTS = (14, 37, 25, 3, 4, 5, 8, 16)
+ATOM_COUNTS = [("g13_dist_atom_counts", f"a{A}") for A in (14, 37, 25, 3, 4, 5, 8, 16)] + \
+              [("g14_dist_small_atom_counts", t) for t in ("a1", "a2", "a6", "a7", "a10", "a13", "a1n7", "a9")]
 
 
-@pytest.mark.parametrize("A", ATOM_COUNTS)
-def test_oracle_matches_reference_at_other_atom_counts(A):
-    """G13 (tools/make_golden_atom_counts.py): the reference's pairwise_distance_matrix at atom14 / atom37 / 25 and
-    the backbone-only layouts, N >= 16 -- sampled whole blocks, exact per-pair mask counts, per-pair distance sums."""
-    g = load_golden("g13_dist_atom_counts")
-    t = f"a{A}"
+@pytest.mark.parametrize("fixture,t", ATOM_COUNTS)
+def test_oracle_matches_reference_at_other_atom_counts(fixture, t):
+    """G13 / G14 (tools/make_golden_atom_counts.py): the reference's pairwise_distance_matrix at atom14 / atom37 / 25,
+    the backbone-only layouts, single atoms (CA traces), atom pairs and the other small counts, at lengths of every
+    alignment phase and below 16 -- sampled whole blocks, exact per-pair mask counts, per-pair distance sums."""
+    g = load_golden(fixture)
     xyz, mask = g[f"{t}_xyz"], g[f"{t}_atom_mask"]
     d, m = O.pairwise_distance_matrix(xyz, mask)
     b, i, j = g[f"{t}_b"].long(), g[f"{t}_i"].long(), g[f"{t}_j"].long()

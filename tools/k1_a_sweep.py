@@ -2,33 +2,47 @@
 interleaved rounds (never compare across runs / boxes): flat=1 (the default dispatch: fixed-A flat pattern kernel
 for atom14 / atom37, any-A flat kernel otherwise), flat=3 (any-A flat kernel), flat=0 (element-per-lane kernel);
 plus the default dispatch with only the distance plane / only the mask plane.
-Arguments: key=value K1 tuning applied to every run (e.g. flat_cpw=2), `json=path` writes the table."""
+Round 3: "r2path" = the round-2 dispatch (k1_small_a=1: odd row-tile kernels + k1_mask_rows for A = 3, 5; flat / any-A /
+element kernels for the other small atom counts) next to the default (row-phase kernel), and "fill" = torch.fill_ on
+the same two buffers (which class of allocation the shape drew).
+Arguments: key=value K1 tuning applied to every run (e.g. flat_cpw=2), `json=path` writes the table,
+`shapes=A:N,A:N,...` replaces the shape list."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)   # no implicit tuning while measuring
 import torch
 from protstruc_amd import _lib, ops
 out_json = None
+shapes = [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4, 500), (5, 512), (5, 500), (5, 501), (8, 256),
+          (3, 512), (3, 500), (3, 501), (16, 256), (25, 128), (1, 512), (1, 500), (1, 501), (2, 512), (2, 501), (7, 512),
+          (7, 500), (10, 512), (10, 500), (6, 501), (13, 250)]
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     if k == "json": out_json = v
+    elif k == "shapes": shapes = [tuple(int(x) for x in sh.split(":")) for sh in v.split(",")]
     else: _lib.set_tuning("k1_" + k, int(v))
 g = torch.Generator().manual_seed(0)
 rows = []
-for A, N in [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4, 500), (5, 512), (5, 500), (5, 501), (8, 256), (3, 512), (3, 500), (3, 501), (16, 256), (25, 128)]:
+for A, N in shapes:
     B = max(1, int(8e9 / (N * N * A * A * 5)))
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
     d = torch.empty(B, N, N, A, A, device="cuda"); m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-    variants = {"default": (1, True, True), "anyA": (3, True, True), "element": (0, True, True),
-                "default_dist_only": (1, True, False), "default_mask_only": (1, False, True)}
+    variants = {"default": (1, True, True, 0), "r2path": (1, True, True, 1), "anyA": (3, True, True, 0),
+                "element": (0, True, True, 0), "default_dist_only": (1, True, False, 0),
+                "default_mask_only": (1, False, True, 0), "fill": None}
     best = {k: float("inf") for k in variants}
     for rnd in range(3):
-        for name, (flat, wd, wm) in variants.items():
+        for name, var in variants.items():
             if name == "element" and rnd > 0: continue    # slow; once is enough
-            _lib.set_tuning("k1_flat", flat)
-            run = lambda: ops.pairwise_distance(xyz, mask, out_dist=d if wd else None, out_mask=m if wm else None,
-                                                want_dist=wd, want_mask=wm)
+            if var is None:
+                run = lambda: (d.fill_(0.0), m.fill_(False))
+            else:
+                flat, wd, wm, small_a = var
+                _lib.set_tuning("k1_flat", flat)
+                _lib.set_tuning("k1_small_a", small_a)
+                run = lambda: ops.pairwise_distance(xyz, mask, out_dist=d if wd else None, out_mask=m if wm else None,
+                                                    want_dist=wd, want_mask=wm)
             for _ in range(2): run()
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -37,12 +51,13 @@ for A, N in [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4
             e1.record(); torch.cuda.synchronize()
             best[name] = min(best[name], e0.elapsed_time(e1) / 5)
     _lib.set_tuning("k1_flat", 1)
-    nbytes = {"default": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1}
-    row = {"A": A, "N": N, "B": B, **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
+    _lib.set_tuning("k1_small_a", 0)
+    nbytes = {"default": 5, "r2path": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
+    row = {"A": A, "N": N, "B": B, "kernel": _lib.k1_plan(B, N, A)["kernel"], "r2_kernel": _lib.k1_plan(B, N, A, small_a=1)["kernel"], **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
                                      for k, v in best.items()}}
     rows.append(row)
-    print(f"A={A:3d} N={N:4d} B={B:5d} " + "  ".join(f"{k} {v['TBps']:5.2f}" for k, v in row.items() if isinstance(v, dict)),
-          flush=True)
+    print(f"A={A:3d} N={N:4d} B={B:5d} " + "  ".join(f"{k} {v['TBps']:5.2f}" for k, v in row.items() if isinstance(v, dict))
+          + f"  [{row['kernel']} | r2: {row['r2_kernel']}]", flush=True)
     del xyz, mask, d, m
 if out_json:
     with open(out_json, "w") as f: json.dump(rows, f, indent=1)

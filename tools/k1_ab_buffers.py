@@ -30,13 +30,22 @@ cfgs = {
     "r1 jt128 +20KB": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=20, k1_flat=1),
     "r1 jt128 +48KB": dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=48, k1_flat=1),
     "r1 jt64 +36KB": dict(k1_rows_per_block=1, k1_jt=64, k1_lds_pad_kb=36, k1_flat=1),
+    # round 3, the bounded small-granule retry: the flat pattern kernel (today's inner loop: hardware sqrt, 34 VALU per
+    # slot) with 64 / 32 / 16 pairs per chunk = 72 / 36 / 18 KB of output per short-lived workgroup instead of 144 KB
+    "flat 64p": dict(k1_flat=2, k1_flat_fl_log2=6), "flat 32p": dict(k1_flat=2, k1_flat_fl_log2=5),
+    "flat 16p": dict(k1_flat=2, k1_flat_fl_log2=4),
+    "flat 32p +8KB": dict(k1_flat=2, k1_flat_fl_log2=5, k1_flat_lds_pad_kb=8),
+    "flat 16p +8KB": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_lds_pad_kb=8),
+    "flat 16p x2": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=2),
+    "flat 16p x4": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=4),
 }
+DEFAULTS = dict(k1_rows_per_block=1, k1_jt=0, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1)
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
         for _ in range(nbuf)]
 
 
 def apply(c):
-    for k, v in c.items():
+    for k, v in {**DEFAULTS, **c}.items():
         _lib.set_tuning(k, v)
 
 
@@ -56,6 +65,17 @@ for rnd in range(3):
             e1.record(); torch.cuda.synchronize()
             best[(name, k)] = min(best[(name, k)], e0.elapsed_time(e1) / 3)
 nb = B * N * N * A * A * 5
+# the class of every buffer, by the rate torch.fill_ writes it
+fill = []
+for d, m in bufs:
+    d.fill_(0.0); m.fill_(False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        d.fill_(0.0); m.fill_(False)
+    e1.record(); torch.cuda.synchronize()
+    fill.append(nb / (e0.elapsed_time(e1) / 3) / 1e9)
 print(f"{'config':16s}" + "".join(f"  buf{k}" for k in range(nbuf)) + "   (TB/s)")
+print(f"{'torch.fill_':16s}" + "".join(f" {f:5.2f}" for f in fill), flush=True)
 for name in cfgs:
     print(f"{name:16s}" + "".join(f" {nb / best[(name, k)] / 1e9:5.2f}" for k in range(nbuf)), flush=True)
