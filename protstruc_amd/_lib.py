@@ -217,6 +217,20 @@ def k1_plan(B, N, A, row_begin=0, row_end=None, *, compact=False, dist_misalign=
             **({"n_workgroups_2": plan.n_workgroups_2, "lds_bytes_2": plan.lds_bytes_2} if plan.n_launches > 1 else {})}
 
 
+_k1_refs = {}      # device index -> (struct, ctypes.byref(struct)) of the device's current settings
+
+
+def k1_config_ref(idx):
+    """``ctypes.byref`` of the cached configuration struct of device ``idx`` (the launch hot path: one dict lookup).
+    The pair (struct, reference) is replaced, never mutated, when a setting changes; the library copies the struct by
+    value before launching."""
+    ent = _k1_refs.get(idx)
+    if ent is None:
+        cfg = k1_config(idx)
+        ent = _k1_refs[idx] = (cfg, ctypes.byref(cfg))
+    return ent[1]
+
+
 def set_tuning(key, value, device=None):
     """Set one K1 knob for ``device`` (default: the current device).  Host-side state only."""
     value = int(value)
@@ -233,6 +247,7 @@ def set_tuning(key, value, device=None):
         idx = _device_index(device)
         _k1_entry(idx)[field] = value
         _k1_structs.pop(idx, None)     # the next launch builds a fresh struct; structs in flight stay as they were
+        _k1_refs.pop(idx, None)
 
 
 def get_tuning(key, device=None):

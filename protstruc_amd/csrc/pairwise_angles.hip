@@ -12,8 +12,10 @@
 // (SRC bit k = 1: point k from j), so all j-only sub-expressions (e.g. d - c for
 // the (2,2) split) are loop-invariant and hoisted out of the i loop, and nothing
 // is selected at run time.  Each store instruction writes 64 consecutive floats
-// of one output row.  4 bytes are written per pair against ~100 flops and an
-// atan2f / acosf: the kernel is VALU-bound, not HBM-bound.
+// of one output row.  4 bytes are written per pair against ~90 flops and an
+// atan2 / acos: the kernel is VALU-bound, not HBM-bound; its
+// arithmetic (triple-product dihedral, polynomial atan2 / acos: ps_common.hpp)
+// is where the 1e-5 parity tolerance is spent.
 #include "ps_common.hpp"
 
 namespace {
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
             p[k] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(s0 + sel.atom[k] * 3), load3(s1 + sel.atom[k] * 3));
         f32x2 v;
         if constexpr (NP == 4)
-            v = dihedral4v(p[0], p[1], p[2], p[3]);
+            v = dihedral4v_k3(p[0], p[1], p[2], p[3]);
         else
             v = angle3v(p[0], p[1], p[2]);
         if (live) {
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
         for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[k] : load3(si + sel.atom[k] * 3);
         float v;
         if constexpr (NP == 4)
-            v = dihedral4(p[0], p[1], p[2], p[3]);
+            v = dihedral4_k3(p[0], p[1], p[2], p[3]);
         else
             v = angle3(p[0], p[1], p[2]);
         if (live) out[((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j] = v;
@@ -129,8 +131,8 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         const f3v cajv = mk3v(ca_j, ca_j), cbjv = mk3v(cb_j, cb_j), ojv = mk3v(o_j, o_j);
         const f32x2 dca = dist3v(cav, cajv), dcb = dist3v(cbv, cbjv), dno = dist3v(nv, ojv);
         const f32x2 ph = angle3v(cav, cbv, cbjv);
-        const f32x2 om = dihedral4v(cav, cbv, cajv, cbjv);   // as coded at protstruc.py:811
-        const f32x2 th = dihedral4v(nv, cav, cbv, cbjv);
+        const f32x2 om = dihedral4v_k3(cav, cbv, cajv, cbjv);   // as coded at protstruc.py:811
+        const f32x2 th = dihedral4v_k3(nv, cav, cbv, cbjv);
         d_ca[o] = dca.x; d_ca[o + N] = dca.y;
         d_cb[o] = dcb.x; d_cb[o + N] = dcb.y;
         d_no[o] = dno.x; d_no[o + N] = dno.y;
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         if (!live) continue;
         const size_t o = ((size_t)b * N + i) * N + j;
         row_planes(o, n_i, ca_i, cb_i, mi_n, mi_ca, mi_cb);
-        omega[o] = dihedral4(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
-        theta[o] = dihedral4(n_i, ca_i, cb_i, cb_j);
+        omega[o] = dihedral4_k3(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
+        theta[o] = dihedral4_k3(n_i, ca_i, cb_i, cb_j);
     }
 }
 

@@ -1627,8 +1627,9 @@ __global__ __launch_bounds__(256) void k1_mask_rows(const uint8_t* __restrict__ 
 //     row's end and the next row's start, which both rows write element-wise (their own elements only);
 //   * the mask plane rides in the same loop: the four mask bytes of a slot's elements are one aligned dword store (byte
 //     offset = float offset of the slot), so it needs neither a 16-byte phase of its own nor a second launch;
-//   * the four row atoms of a slot's elements are LDS reads (broadcasts: many lanes read the same few atoms); for A = 1
-//     there is a single row atom, read once per row.
+//   * the four row atoms of a slot's elements are LDS reads (broadcasts: many lanes read the same few atoms) whose
+//     fourth component carries the atom's mask bit; for A = 1 there is a single row atom, read once per row;
+//   * everything per row (phase, row pointer, LDS row address) is wave-uniform and rides in SGPRs.
 template <int A>
 struct RowPhase {
     static_assert(A >= 1 && A <= 13, "row-phase kernel: small atom counts");
@@ -1641,37 +1642,41 @@ struct RowPhase {
     static constexpr int MAXRES = (4 * TS + 2) / AA + 2;   // column residues a tile's elements can touch
 };
 
+// One slot of one row.  `xi_row`: LDS address of the row residue's atoms (uniform over the wave); od / om point at the slot
+// (float / byte offset 4 s - ph of the row run); PH = the row's phase.  The row atom of every element arrives as one
+// ds_read_b128 whose fourth component is that atom's mask bit (0 / 1 as an integer), so the mask costs no second lookup.
 template <int A, bool EXACT, int PH>
-__device__ __forceinline__ void rowphase_row(const float4* __restrict__ sxi_row, uint32_t mi, const float (&col)[7][3],
-                                             uint32_t aw, uint32_t cm, uint32_t valid, float* __restrict__ od,
-                                             uint8_t* __restrict__ om) {
-    // one slot of one row: od / om point at the slot (float / byte offset 4 s - ph of the row run), PH = the row's phase
+__device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, const float (&col)[7][3],
+                                              const uint32_t (&aoff)[7], uint32_t cm, uint32_t valid,
+                                              float* __restrict__ od_, uint8_t* __restrict__ om_, bool wd, bool wm) {
+    // wd / wm: whether the distance / mask plane is produced (uniform); the pointers are only meaningful when set
+    float* od = wd ? od_ : nullptr;
+    uint8_t* om = wm ? om_ : nullptr;
     using T = RowPhase<A>;
     constexpr int WO = T::W0 - PH;                     // window element of the slot's first element
     const uint32_t vm = (valid >> WO) & 15u;
     if (vm == 0u) return;
     float v[4];
-    uint32_t rowbits = 0;
+    uint32_t rowbytes = 0;                             // byte k = mask bit of element k's row atom
     float4 xi0;
-    if (A == 1) xi0 = sxi_row[0];
+    if (A == 1) xi0 = *reinterpret_cast<const float4*>(xi_row);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const uint32_t a = (A == 1) ? 0u : ((aw >> (4 * (WO + k))) & 15u);
-        const float4 xi = (A == 1) ? xi0 : sxi_row[a];
+        const float4 xi = (A == 1) ? xi0 : *reinterpret_cast<const float4*>(xi_row + aoff[WO + k]);
         v[k] = dist_pp<EXACT>(xi, make_float4(col[WO + k][0], col[WO + k][1], col[WO + k][2], 0.f));
-        rowbits |= ((mi >> a) & 1u) << k;
+        rowbytes |= __float_as_uint(xi.w) << (8 * k);
     }
-    const uint32_t m4 = rowbits & (cm >> WO) & 15u;
+    const uint32_t mw = rowbytes & spread4((cm >> WO) & 15u);
     if (vm == 15u) {
-        if (od) store16<false>(od, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+        if (wd) store16<false>(od, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                               __float_as_uint(v[3])));
-        if (om) *reinterpret_cast<uint32_t*>(om) = spread4(m4);
+        if (wm) *reinterpret_cast<uint32_t*>(om) = mw;
     } else {   // the slot that holds a row's start or end: this row's elements only
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if ((vm >> k) & 1u) {
-                if (od) od[k] = v[k];
-                if (om) om[k] = (uint8_t)((m4 >> k) & 1u);
+                if (wd) od[k] = v[k];
+                if (wm) om[k] = (uint8_t)((mw >> (8 * k)) & 1u);
             }
     }
 }
@@ -1682,13 +1687,12 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                             int N, int row_begin, int row_end, int out_rows,
                                                             int out_row_origin, int IR, int n_tiles, int spt,
-                                                            int n_ichunks, int xcd_remap) {
+                                                            int n_ichunks, int lpg_log2, int xcd_remap) {
     using T = RowPhase<A>;
     constexpr int AA = T::AA, W = T::W;
     extern __shared__ __attribute__((aligned(16))) char smem_rp[];
-    float4* sxi = reinterpret_cast<float4*>(smem_rp);                   // [IR * A] row atoms
-    uint32_t* smi = reinterpret_cast<uint32_t*>(sxi + IR * A);          // [IR] row mask bits
-    uint32_t* smj = smi + IR;                                           // [MAXRES] column mask bits
+    float4* sxi = reinterpret_cast<float4*>(smem_rp);                   // [IR * A] row atoms: x, y, z, mask bit
+    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A);          // [MAXRES] column mask bits
     float* sxj = reinterpret_cast<float*>(smj + T::MAXRES);             // [MAXRES * A * 3] column coordinates, as in HBM
 
     const int tid = threadIdx.x;
@@ -1702,8 +1706,13 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
     const int in = min(IR, row_end - i0);
     const int nel = N * AA;                                             // elements of one row run
-    const int nslots = T::PHASED ? (nel + 6) / 4 : nel / 4;            // slots a row can touch, over all phases
+    const int nslots = (nel + 3 + ((nel & 3) == 0 ? 0 : (nel & 3) == 2 ? 2 : 3)) / 4;   // slots a row can touch, over the phases that occur
     const int s0 = (int)tile * spt, s1 = min(s0 + spt, nslots);
+    // Short rows (a CA trace of 512 residues is 128 slots): the 256 lanes split into 256 >> lpg_log2 row groups of
+    // LPG lanes (whole waves); group g takes rows g, g + G, ... so that no lane idles.  A lane's slots are LPG apart.
+    const int LPG = 1 << lpg_log2, G = 256 >> lpg_log2;
+    const int grp = __builtin_amdgcn_readfirstlane(tid >> lpg_log2);    // uniform over the wave: everything per row is scalar
+    const int sl = tid & (LPG - 1);
     // column residues the tile's elements 4 s0 - 3 .. 4 s1 - 1 belong to
     const int t_lo = max(4 * s0 - T::W0, 0), t_hi = min(4 * s1 - 1, nel - 1);
     const int j_lo = t_lo / AA, j_hi = t_hi / AA, nres = j_hi - j_lo + 1;
@@ -1717,31 +1726,33 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
             const int atom = f / 3, comp = f - atom * 3;
             li[atom * 4 + comp] = gi[f];
         }
-        for (int r = tid; r < nres + in; r += 256) {
-            const bool is_j = r < nres;
-            const int rl = is_j ? r : r - nres;
+        for (int f = tid; f < in * A; f += 256)      // fourth component: the row atom's mask bit
+            reinterpret_cast<uint32_t*>(sxi)[f * 4 + 3] = amask ? (amask[((size_t)b * N + i0) * A + f] != 0 ? 1u : 0u) : 1u;
+        for (int r = tid; r < nres; r += 256) {
             uint32_t bits = (1u << A) - 1u;
             if (amask) {
-                const uint8_t* m = amask + ((size_t)b * N + (is_j ? j_lo : i0) + rl) * A;
+                const uint8_t* m = amask + ((size_t)b * N + j_lo + r) * A;
                 bits = 0;
 #pragma unroll
                 for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
             }
-            (is_j ? smj : smi)[rl] = bits;
+            smj[r] = bits;
         }
     }
     __syncthreads();
 
-    // per-lane pattern: column atom, row-atom index, column mask bit and validity of every window element
+    // per-lane pattern: column atom, row-atom offset, column mask bit and validity of every window element
     float col[T::SPL][7][3];
-    uint32_t aw[T::SPL], cm[T::SPL], valid[T::SPL];
+    uint32_t aoff[T::SPL][7], cm[T::SPL], valid[T::SPL], so[T::SPL];
 #pragma unroll
     for (int u = 0; u < T::SPL; ++u) {
-        const int s = s0 + 256 * u + tid;
-        aw[u] = cm[u] = valid[u] = 0;
+        const int s = s0 + LPG * u + sl;
+        so[u] = 4u * (unsigned)s;
+        cm[u] = valid[u] = 0;
 #pragma unroll
         for (int wi = 0; wi < 7; ++wi) {
             col[u][wi][0] = col[u][wi][1] = col[u][wi][2] = 0.f;
+            aoff[u][wi] = 0;
             if (wi < W) {
                 const int t = 4 * s - T::W0 + wi;
                 const bool ok = s < s1 && t >= 0 && t < nel;
@@ -1752,7 +1763,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                 col[u][wi][0] = p[0];
                 col[u][wi][1] = p[1];
                 col[u][wi][2] = p[2];
-                aw[u] |= a << (4 * wi);
+                aoff[u][wi] = a * (unsigned)sizeof(float4);
                 cm[u] |= (ok ? ((smj[j - (unsigned)j_lo] >> c) & 1u) : 0u) << wi;
                 valid[u] |= (ok ? 1u : 0u) << wi;
             }
@@ -1762,25 +1773,26 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     const long long Rb = (long long)b * out_rows - out_row_origin;    // absolute row of the buffer = Rb + i
     const unsigned nel4 = (unsigned)nel & 3u;
 #pragma unroll 1
-    for (int il = 0; il < in; ++il) {
+    for (int il = grp; il < in; il += G) {
         const long long R = Rb + i0 + il;
-        const unsigned ph = T::PHASED ? (((unsigned)(R & 3) * nel4) & 3u) : 0u;    // (R * nel) mod 4: uniform
-        const size_t rowoff = (size_t)R * (size_t)nel;
-        const float4* xi = sxi + il * A;
-        const uint32_t mi = smi[il];
+        const unsigned ph = T::PHASED ? (((unsigned)(R & 3) * nel4) & 3u) : 0u;    // (R * nel) mod 4
+        const long long base = R * (long long)nel - (long long)ph;     // float index of row element -ph: 16-byte aligned, >= 0
+        float* rd = dist + base;          // (only dereferenced when the plane is requested)
+        uint8_t* rm = dmask + base;
+        const bool wd = dist != nullptr, wm = dmask != nullptr;
+        const char* xi_row = reinterpret_cast<const char*>(sxi + il * A);
 #pragma unroll
         for (int u = 0; u < T::SPL; ++u) {
-            const long long eo = 4ll * (s0 + 256 * u + tid) - (long long)ph;   // row element of the slot's first float
-            float* od = dist ? dist + rowoff + eo : nullptr;
-            uint8_t* om = dmask ? dmask + rowoff + eo : nullptr;
+            float* od = rd + so[u];
+            uint8_t* om = rm + so[u];
             if constexpr (!T::PHASED) {
-                rowphase_row<A, EXACT, 0>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om);
+                rowphase_slot<A, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm);
             } else {
-                switch (ph) {   // uniform over the workgroup
-                    case 0: rowphase_row<A, EXACT, 0>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
-                    case 1: rowphase_row<A, EXACT, 1>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
-                    case 2: rowphase_row<A, EXACT, 2>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
-                    default: rowphase_row<A, EXACT, 3>(xi, mi, col[u], aw[u], cm[u], valid[u], od, om); break;
+                switch (ph) {   // uniform over the wave
+                    case 0: rowphase_slot<A, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 1: rowphase_slot<A, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 2: rowphase_slot<A, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    default: rowphase_slot<A, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
                 }
             }
         }
@@ -2267,25 +2279,27 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
                     int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     using T = RowPhase<A>;
     const int rows = row_end - row_begin;
-    const int n_ichunks = (rows + 31) / 32, IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 rows, balanced
     const int nel = N * T::AA;
-    const int nslots = T::PHASED ? (nel + 6) / 4 : nel / 4;
-    const int n_tiles = (nslots + T::TS - 1) / T::TS;
+    const int nslots = (nel + 3 + ((nel & 3) == 0 ? 0 : (nel & 3) == 2 ? 2 : 3)) / 4;   // over the phases that occur
+    // short rows: 2 or 4 row groups of 128 / 64 lanes (every lane still takes ~32 rows), see the kernel
+    const int lpg_log2 = nslots <= 128 ? 6 : (nslots <= 256 ? 7 : 8);
+    const int G = 256 >> lpg_log2, tile_slots = T::SPL << lpg_log2;
+    const int n_ichunks = (rows + 32 * G - 1) / (32 * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 G rows, balanced
+    const int n_tiles = (nslots + tile_slots - 1) / tile_slots;
     int spt = (nslots + n_tiles - 1) / n_tiles;          // slots per tile-row, balanced over the tiles, whole waves
     spt = ((spt + 63) / 64) * 64;
-    if (spt > T::TS) spt = T::TS;
-    const unsigned long long n_wg = (unsigned long long)n_tiles * ((rows + IR - 1) / IR) * B;
+    if (spt > tile_slots) spt = tile_slots;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
-    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)IR * 4 + (size_t)T::MAXRES * 4 +
-                       (size_t)T::MAXRES * A * 3 * sizeof(float);
+    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)T::MAXRES * 4 + (size_t)T::MAXRES * A * 3 * sizeof(float);
     if (g.exact_sqrt)
         return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, true>, dim3((unsigned)n_wg),
                      dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR,
-                     n_tiles, spt, (rows + IR - 1) / IR, remap);
+                     n_tiles, spt, n_ichunks, lpg_log2, remap);
     return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, false>, dim3((unsigned)n_wg),
                  dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles,
-                 spt, (rows + IR - 1) / IR, remap);
+                 spt, n_ichunks, lpg_log2, remap);
 }
 
 bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }

@@ -164,6 +164,50 @@ __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
     return atan2_ps(y, x);
 }
 
+// atan2 of the PAIRWISE kernels (K3 and the fused featuriser; K2 and the pointwise entry keep atan2_ps with every IEEE
+// special case).  Same polynomial, same quadrant logic, same signed-zero behaviour (atan2(+0, +0) = +0, atan2(+0, -0) =
+// pi); what is dropped are six per-element compare / select instructions that only matter for infinite arguments:
+//   * max(|x|, |y|) is clamped below at FLT_MIN inside the same v_max3_f32, which makes 0 / 0 come out as 0 without the
+//     separate (mx == 0) select;
+//   * NaN is re-injected with two fused multiply-adds by zero (v_min / v_max drop NaNs) instead of two compares, an or
+//     and a select;
+//   * atan2(+-inf, +-inf) and atan2(finite, +-inf) come out NaN instead of multiples of pi / 4.  x and y are dot
+//     products of cross products of coordinate differences: they overflow only for coordinates beyond 4e9 A.
+__device__ __forceinline__ float atan2_k3(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(fmaxf(ax, ay), 1.17549435e-38f), mn = fminf(ax, ay);
+    const float a = mn * __builtin_amdgcn_rcpf(mx);
+    const float s = a * a;
+    float p = 0.0028340641874819994f;
+    p = __builtin_fmaf(p, s, -0.016005029901862144f);
+    p = __builtin_fmaf(p, s, 0.042587608098983765f);
+    p = __builtin_fmaf(p, s, -0.07495445758104324f);
+    p = __builtin_fmaf(p, s, 0.10636754333972931f);
+    p = __builtin_fmaf(p, s, -0.14202570915222168f);
+    p = __builtin_fmaf(p, s, 0.19992484152317047f);
+    p = __builtin_fmaf(p, s, -0.3333306610584259f);
+    p = __builtin_fmaf(p, s, 1.0f);
+    float r = a * p;
+    r = (ay > ax) ? (1.5707963267948966f - r) : r;
+    r = (__float_as_uint(x) >> 31) ? (3.141592653589793f - r) : r;
+    r = __builtin_fmaf(x, 0.0f, __builtin_fmaf(y, 0.0f, r));   // r >= +0 here: adding +-0 leaves it, NaN / inf poison it
+    return copysignf(r, y);
+}
+
+// dihedral4 with atan2_k3 and without the leading `0 +` of the one dot product whose terms are squares (b1 . b1: its
+// terms are never -0, so the sum is the same bits)
+__device__ __forceinline__ float dihedral4_k3(f3 a, f3 b, f3 c, f3 d) {
+    f3 b0 = sub3(a, b);
+    f3 b1 = sub3(c, b);
+    f3 b2n = sub3(c, d);
+    f3 n1 = cross3(b0, b1);
+    f3 n2 = cross3(b1, b2n);
+    const float nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
+    float x = dot3(n1, n2) * __builtin_amdgcn_rsqf(nn);
+    float y = dot3(n1, b2n);
+    return atan2_k3(y, x);
+}
+
 // ---- two problems per lane: the same arithmetic on float2, which gfx950 issues as packed v_pk_* instructions ----
 // (K3 is VALU-issue bound; element for element the operations and their order are those of the scalar code above,
 // so the results are bit-identical.)
@@ -228,6 +272,43 @@ __device__ __forceinline__ f32x2 dihedral4v(f3v a, f3v b, f3v c, f3v d) {
     const f32x2 x = dot3v(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
     const f32x2 y = dot3v(n1, b2n);
     return atan2_ps_v(y, x);
+}
+
+// atan2_k3 / dihedral4_k3 on both halves (same operations in the same order per element, hence the same bits)
+__device__ __forceinline__ f32x2 atan2_k3_v(f32x2 y, f32x2 x) {
+    const f32x2 ax = {fabsf(x.x), fabsf(x.y)}, ay = {fabsf(y.x), fabsf(y.y)};
+    const f32x2 mx = {fmaxf(fmaxf(ax.x, ay.x), 1.17549435e-38f), fmaxf(fmaxf(ax.y, ay.y), 1.17549435e-38f)};
+    const f32x2 mn = {fminf(ax.x, ay.x), fminf(ax.y, ay.y)};
+    const f32x2 a = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    const f32x2 s = a * a;
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 p = k2(0.0028340641874819994f);
+    p = __builtin_elementwise_fma(p, s, k2(-0.016005029901862144f));
+    p = __builtin_elementwise_fma(p, s, k2(0.042587608098983765f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.07495445758104324f));
+    p = __builtin_elementwise_fma(p, s, k2(0.10636754333972931f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.14202570915222168f));
+    p = __builtin_elementwise_fma(p, s, k2(0.19992484152317047f));
+    p = __builtin_elementwise_fma(p, s, k2(-0.3333306610584259f));
+    p = __builtin_elementwise_fma(p, s, k2(1.0f));
+    f32x2 r = a * p;
+    const f32x2 rq = k2(1.5707963267948966f) - r;
+    r.x = (ay.x > ax.x) ? rq.x : r.x;
+    r.y = (ay.y > ax.y) ? rq.y : r.y;
+    const f32x2 rh = k2(3.141592653589793f) - r;
+    r.x = (__float_as_uint(x.x) >> 31) ? rh.x : r.x;
+    r.y = (__float_as_uint(x.y) >> 31) ? rh.y : r.y;
+    r = __builtin_elementwise_fma(x, k2(0.0f), __builtin_elementwise_fma(y, k2(0.0f), r));
+    return f32x2{copysignf(r.x, y.x), copysignf(r.y, y.y)};
+}
+
+__device__ __forceinline__ f32x2 dihedral4v_k3(f3v a, f3v b, f3v c, f3v d) {
+    const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2n = sub3v(c, d);
+    const f3v n1 = cross3v(b0, b1), n2 = cross3v(b1, b2n);
+    const f32x2 nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
+    const f32x2 x = dot3v(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+    const f32x2 y = dot3v(n1, b2n);
+    return atan2_k3_v(y, x);
 }
 
 // acos_ps on both halves (same operations in the same order per element)

@@ -36,13 +36,15 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 
 def _u8c(t: Optional[torch.Tensor], name: str) -> Optional[torch.Tensor]:
-    """Truth value of a mask as contiguous uint8 0/1 (bool tensors are reinterpreted, not copied)."""
+    """A mask as a contiguous one-byte-per-entry tensor for the kernels, which test every byte against zero (C ABI:
+    "any non-zero input byte counts as true"): bool and uint8 tensors are passed as they are -- only their address is
+    used, so not even a reinterpreting view is created -- anything else is reduced to its truth value first."""
     if t is None:
         return None
     _require_device(t, name)
-    if t.dtype == torch.bool:
-        return t.contiguous().view(torch.uint8)
-    return (t != 0).contiguous().view(torch.uint8)
+    if t.dtype == torch.bool or t.dtype == torch.uint8:
+        return t.contiguous()
+    return (t != 0).contiguous()
 
 
 def _check_rng_state(rng_state: Optional[torch.Tensor], device: torch.device) -> None:
@@ -79,7 +81,14 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# torch's current HIP stream of a device as a raw handle: the private accessor torch's own kernel launchers use
+# (0.1 us) where it exists, else the public Stream object (1.2 us per call)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream(t: torch.Tensor):
+    if _raw_stream is not None:
+        return _raw_stream(t.device.index)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
@@ -112,13 +121,33 @@ def _on(device: torch.device):
 # (tools/k1_ab_buffers.py, profiles/r02_k1_ab_buffers.log).  That configuration is therefore simply the default
 # (ps_k1_config_default), and nothing is timed behind the caller's back any more.  The tuner remains as an explicit
 # call -- ops.autotune_pairwise_distance(), which bench.py makes before its warm-up and reports -- or with
-# PROTSTRUC_AMD_AUTOTUNE=1 on the first large call of each kind per device; it writes that DEVICE's entry of the
+# PROTSTRUC_AMD_AUTOTUNE=1 (read at import; ops.set_implicit_autotune at run time) on the first large call of each kind
+# per device; it writes that DEVICE's entry of the
 # host-side table in _lib.py (per-call argument to the library; other devices and threads are never affected) and
 # never runs during stream capture.
 _K1_TUNED = {}
 _K1_TUNE_LOCK = threading.Lock()
+import os as _os
+_AUTOTUNE_ENV = bool(_os.environ.get("PROTSTRUC_AMD_AUTOTUNE"))   # read once, at import: the launch path does no environment lookups
+
+
+def set_implicit_autotune(flag: bool) -> None:
+    """Opt in to (or out of) tuning K1's launch configuration on the first large call of each kind per device -- what
+    ``PROTSTRUC_AMD_AUTOTUNE=1`` in the environment at import time selects.  Off by default."""
+    global _AUTOTUNE_ENV
+    _AUTOTUNE_ENV = bool(flag)
+
+
+def _k1_launch_entry(*args):
+    """First call: bind the library's entry point, then replace this trampoline with it."""
+    global _K1_LAUNCH
+    _K1_LAUNCH = _lib.load().ps_pairwise_distance_cfg_f32
+    return _K1_LAUNCH(*args)
+
+
+_K1_LAUNCH = _k1_launch_entry
 # Candidates of the explicit tuner, as ps_k1_config fields.  The default comes first: the choice moves away from it
-# only for a clear (>= 1.5 %) gain.  Pattern kernel (N % 16 == 0): rows per workgroup, KB of idle LDS per workgroup
+# only for a clear (>= 1 %) gain.  Pattern kernel (N % 16 == 0): rows per workgroup, KB of idle LDS per workgroup
 # (only lowers the number of resident workgroups per CU: fewer concurrent store streams) and column residues per
 # tile.  What the second measurement on 6 + 8 buffers showed (profiles/r02_k1_ab_buffers.log): fast buffers like the
 # 64-residue tile + 8 KB best (7.1-7.2 TB/s against 7.0), slow buffers a hard cap of 2 workgroups per CU (64-residue
@@ -146,9 +175,7 @@ def _cand_label(c) -> str:
 
 
 def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False) -> None:
-    import os
-
-    if not force and not os.environ.get("PROTSTRUC_AMD_AUTOTUNE"):
+    if not force and not _AUTOTUNE_ENV:   # (the hot path does not even get here: see the caller)
         return
     if A != 15 or N < 16 or n_pairs < (1 << 22):
         return
@@ -193,7 +220,7 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False
                 timings[k] = min(timings[k], e0.elapsed_time(e1) / 2)
         best = 0
         for k in range(1, len(candidates)):
-            if timings[k] < timings[best] * 0.985:   # prefer the earlier candidate unless the gain is clear
+            if timings[k] < timings[best] * 0.99:   # prefer the earlier candidate unless the gain is clear (1 %)
                 best = k
         for field, value in candidates[best].items():
             _lib.set_tuning("k1_" + field, value, device)
@@ -306,12 +333,14 @@ def pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = Non
         if want_mask:
             dmask = out_mask if out_mask is not None else torch.empty(shape, dtype=torch.bool, device=xyz.device)
         args = (_ptr(xyz), _ptr(mask_u8), _ptr(dist), _ptr(dmask), B, N, A, row_begin, row_end, out_rows, origin)
-        _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A, force=_autotune)
-        cfg = _lib.k1_config(xyz.device)   # this device's settings, snapshotted for this launch
+        if _autotune or _AUTOTUNE_ENV:
+            _autotune_k1(xyz.device, args, B * (row_end - row_begin) * N, N, A, force=_autotune)
+        cfg_ref = _lib.k1_config_ref(xyz.device.index)   # this device's settings, snapshotted for this launch
         rc = 0
         if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
-            rc = _lib.load().ps_pairwise_distance_cfg_f32(*args, ctypes.byref(cfg), _stream(xyz))
-    _lib.check(rc, "ps_pairwise_distance_cfg_f32")
+            rc = _K1_LAUNCH(*args, cfg_ref, _stream(xyz))
+    if rc:
+        _lib.check(rc, "ps_pairwise_distance_cfg_f32")
     return dist, dmask
 
 

@@ -1,0 +1,50 @@
+"""One table of K1 launches, one per kernel family behind ``ps_pairwise_distance_cfg_f32``.
+
+Used twice: ``tests/test_k1_plan.py`` (CPU) asserts through the library's own dispatcher (``ps_k1_plan_f32``) that each
+entry selects the family it names and that every family the dispatcher can report appears in the table;
+``tests/test_gpu_parity.py::test_k1_every_kernel_family_vs_oracle`` runs exactly these launches on the GPU against the
+oracle.  Together: every kernel family is reached by a shape that is held to the oracle.
+
+Entry: (B, N, A, (row_begin, row_end) or None, compact, {K1 tuning overrides}, expected family)."""
+
+FAMILY_SHAPES = [
+    # A = 15: pattern (N % 16 == 0), flat pattern (any other N >= 16), slot-decode (N < 16, or the simple variant)
+    (2, 64, 15, None, False, {}, "pattern"),
+    (2, 256, 15, (64, 128), False, {}, "pattern"),
+    (3, 50, 15, None, False, {}, "flat"),
+    (2, 37, 15, (5, 30), True, {}, "flat"),
+    (2, 64, 15, None, False, {"k1_flat": 2, "k1_flat_fl_log2": 5}, "flat"),
+    (2, 12, 15, None, False, {}, "slot_decode"),
+    (2, 48, 15, None, False, {"k1_variant": 1}, "slot_decode"),
+    # fixed-A flat pattern kernels: A*A >= 129 (flatA) and A*A <= 128 (flatS, reached with k1_flat = 4)
+    (2, 40, 14, None, False, {}, "flatA"),
+    (1, 20, 37, (3, 17), False, {}, "flatA"),
+    (2, 33, 25, None, False, {}, "flatA"),
+    (2, 40, 5, None, False, {"k1_flat": 4}, "flatS"),
+    (2, 21, 8, (2, 19), True, {"k1_flat": 4}, "flatS"),
+    # row-tile kernels of A = 4, 8
+    (2, 40, 4, None, False, {}, "rowtile"),
+    (2, 33, 8, (1, 32), False, {}, "rowtile"),
+    # row-phase kernel (round 3): every other atom count up to 13, any length
+    (3, 33, 1, None, False, {}, "rowphase"),
+    (2, 18, 2, None, False, {}, "rowphase"),
+    (2, 21, 5, (4, 20), True, {}, "rowphase"),
+    (2, 40, 7, None, False, {}, "rowphase"),
+    (1, 30, 13, None, False, {}, "rowphase"),
+    (2, 6, 3, None, False, {}, "rowphase"),
+    # the round-2 odd row-tile paths (k1_small_a = 1): aligned, N % 4 == 0 (+ k1_mask_rows), any other N (phased)
+    (2, 32, 5, None, False, {"k1_small_a": 1}, "rowtile_odd"),
+    (2, 20, 5, None, False, {"k1_small_a": 1}, "rowtile_odd + mask_rows"),
+    (2, 21, 3, (3, 18), False, {"k1_small_a": 1}, "rowtile_odd_phased + mask_rows"),
+    # any-A flat kernel: atom counts without a fixed-A kernel
+    (2, 40, 20, None, False, {}, "anyA"),
+    (2, 17, 33, (0, 9), True, {}, "anyA"),
+    (2, 40, 7, None, False, {"k1_small_a": 1}, "anyA"),
+    # element-per-lane kernel: A > 64, N < 16 without a row-phase kernel, or the simple variant
+    (1, 8, 70, None, False, {}, "element"),
+    (2, 10, 20, None, False, {}, "element"),
+    (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
+]
+
+ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "flatS", "rowtile", "rowphase", "rowtile_odd",
+                "rowtile_odd + mask_rows", "rowtile_odd_phased + mask_rows", "anyA", "element"}

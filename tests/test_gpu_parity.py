@@ -98,6 +98,80 @@ def test_k1_vs_oracle(SB, B, N):
     assert torch.equal(m.cpu(), rm)
 
 
+def test_k1_every_kernel_family_vs_oracle(SB):
+    """tests/k1_families.py: one launch per kernel family behind the K1 entry point.  Each entry is first confirmed --
+    through the library's own dispatcher, for the very buffers used -- to select the family it names, then run on the
+    GPU and held to the oracle (distances 1e-5 with NaN positions exact, mask exact), with sentinels around the output
+    and, for row ranges written into a full-size buffer, in the rows that must stay untouched."""
+    from protstruc_amd import _lib, ops
+    from tests.k1_families import ALL_FAMILIES, FAMILY_SHAPES
+    keys = sorted({k for e in FAMILY_SHAPES for k in e[5]})
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    SENT, ran = 777.0, set()
+    try:
+        for B, N, A, rows, compact, overrides, family in FAMILY_SHAPES:
+            for k in keys:
+                _lib.set_tuning(k, overrides.get(k, saved[k]))
+            xyz, mask = synth(900 + 7 * N + A, B, N, A=A)
+            xyz[B - 1, N // 2, A - 1] = float("nan")
+            r0, r1 = rows if rows else (0, N)
+            out_rows = (r1 - r0) if compact else N
+            numel, pad = B * out_rows * N * A * A, 64
+            bd = torch.full((numel + 2 * pad,), SENT, device="cuda")
+            bm = torch.full((numel + 2 * pad,), 7, dtype=torch.uint8, device="cuda")
+            d = bd[pad:pad + numel].view(B, out_rows, N, A, A)
+            m = bm[pad:pad + numel].view(torch.bool).view(B, out_rows, N, A, A)
+            plan = _lib.k1_plan(B, N, A, r0, r1, compact=compact, dist_misalign=d.data_ptr() % 16,
+                                mask_misalign=m.data_ptr() % 16)
+            assert plan["family"] == family, (B, N, A, rows, overrides, plan)
+            ops.pairwise_distance(xyz.cuda(), mask.cuda(), row_begin=r0, row_end=r1, compact=compact, out_dist=d, out_mask=m)
+            rd, rm = O.pairwise_distance_matrix(xyz, mask)
+            got_d = d if compact else d[:, r0:r1]
+            got_m = m if compact else m[:, r0:r1]
+            assert_close(got_d, rd[:, r0:r1])
+            assert torch.equal(got_m.cpu(), rm[:, r0:r1]), (family, B, N, A)
+            assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all(), (family, B, N, A)
+            assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all(), (family, B, N, A)
+            if not compact:
+                assert (d[:, :r0] == SENT).all() and (d[:, r1:] == SENT).all(), (family, B, N, A)
+                raw = bm[pad:pad + numel].view(B, N, N, A, A)
+                assert (raw[:, :r0] == 7).all() and (raw[:, r1:] == 7).all(), (family, B, N, A)
+            ran.add(family)
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+    assert ran == ALL_FAMILIES
+
+
+def test_k1_config2_exact_shape(SB):
+    """BASELINE config 2's K1 half at its exact shape (B=64, N=256; 4.7 GB of output): sampled blocks against the oracle's
+    formula, exact mask checksum of every structure, bitwise symmetry of two structures, no element left unwritten."""
+    from protstruc_amd import _lib, ops
+    B, N = 64, 256
+    xyz, mask = synth(2, B, N)
+    xg, mg = xyz.cuda(), mask.cuda()
+    d = torch.full((B, N, N, 15, 15), float("nan"), device="cuda")
+    m = torch.zeros(B, N, N, 15, 15, dtype=torch.bool, device="cuda")
+    assert _lib.k1_plan(B, N, 15)["kernel"] == "k1_pairdist_a15_pat<128>"
+    ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
+    g = torch.Generator().manual_seed(22)
+    bs = torch.randint(0, B, (256,), generator=g)
+    is_ = torch.cat([torch.randint(0, N, (252,), generator=g), torch.tensor([0, N - 1, N - 1, 0])])
+    js = torch.cat([torch.randint(0, N, (252,), generator=g), torch.tensor([0, N - 1, 0, N - 1])])
+    want = torch.norm(xyz[bs, is_][:, :, None, :] - xyz[bs, js][:, None, :, :], dim=-1)
+    assert_close(d[bs.cuda(), is_.cuda(), js.cuda()], want)
+    assert torch.equal(m[bs.cuda(), is_.cuda(), js.cuda()].cpu(), mask[bs, is_][:, :, None] & mask[bs, js][:, None, :])
+    per_struct = mask.reshape(B, -1).sum(1).to(torch.int64)
+    assert torch.equal(torch.stack([torch.count_nonzero(m[b]) for b in range(B)]).cpu(), per_struct * per_struct)
+    assert not torch.isnan(d).any()
+    for b in (0, B - 1):
+        assert torch.equal(d[b], d[b].permute(1, 0, 3, 2))
+    # one structure in full against the oracle
+    rd, rm = O.pairwise_distance_matrix(xyz[17:18], mask[17:18])
+    assert_close(d[17:18], rd)
+    assert torch.equal(m[17:18].cpu(), rm)
+
+
 @pytest.mark.parametrize("A,N", [(15, 16), (15, 21), (14, 18), (5, 20), (37, 16), (7, 12), (4, 9), (4, 131), (8, 33), (8, 7), (5, 32), (3, 16), (5, 20), (3, 28), (5, 21), (3, 18), (5, 7)])
 def test_k1_special_values(SB, A, N):
     """Infinite, huge, tiny, NaN and signed-zero coordinates propagate exactly as in the reference's arithmetic
@@ -620,7 +694,7 @@ def test_k1_allocate_fast_outputs(SB):
 
 def test_k1_autotune_is_explicit_and_transparent(SB):
     """Nothing is timed behind the caller's back: a large call leaves the device's configuration alone.  The explicit
-    tuner (ops.autotune_pairwise_distance) and the PROTSTRUC_AMD_AUTOTUNE=1 opt-in change speed only -- results are
+    tuner (ops.autotune_pairwise_distance) and the PROTSTRUC_AMD_AUTOTUNE=1 / set_implicit_autotune opt-in change speed only -- results are
     bit-identical before and after -- and never run during stream capture."""
     import os
     from protstruc_amd import _lib, ops
@@ -643,7 +717,7 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         assert torch.equal(d0, d1) and torch.equal(m0, m1)
         # opt-in through the environment; a captured call never tunes and still works
         ops._K1_TUNED.pop(xg.device, None)
-        os.environ["PROTSTRUC_AMD_AUTOTUNE"] = "1"
+        ops.set_implicit_autotune(True)     # what PROTSTRUC_AMD_AUTOTUNE=1 at import time selects
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             d2, m2 = ops.pairwise_distance(xg, mg)
@@ -654,7 +728,7 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         # the flat kernel's chunks per workgroup (lengths that are not a multiple of 16) tune the same way
         xyz2, mask2 = synth(13, 23, 437)   # 4.39 M pairs
         x2, m2g = xyz2.cuda(), mask2.cuda()
-        os.environ.pop("PROTSTRUC_AMD_AUTOTUNE")
+        ops.set_implicit_autotune(False)
         e0, f0 = ops.pairwise_distance(x2, m2g)
         assert "flat_cpw" not in ops.k1_autotune_result(xg.device)
         e1, f1 = torch.empty_like(e0), torch.empty_like(f0)
@@ -663,7 +737,7 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         assert _lib.get_tuning("k1_flat_lds_pad_kb") == res2["flat_lds_pad_kb"]
         assert torch.equal(e0, e1) and torch.equal(f0, f1)
     finally:
-        os.environ.pop("PROTSTRUC_AMD_AUTOTUNE", None)
+        ops.set_implicit_autotune(False)
         for k, v in (("k1_rows_per_block", rows0), ("k1_lds_pad_kb", pad0), ("k1_jt", 0), ("k1_flat_cpw", 1),
                      ("k1_flat_lds_pad_kb", 0)):
             _lib.set_tuning(k, v)

@@ -42,6 +42,16 @@ rows = [
     ("sb.inter_residue_geometry()", lambda: sb.inter_residue_geometry()),
     ("sb.diffuse_xyz(beta)", lambda: sb.diffuse_xyz(beta)),
     ("torch.empty + torch.add (reference point)", lambda: torch.add(xg, 1.0)),
+    # config 5's eager step: diffuse_xyz + backbone_orientations
+    ("config-5 eager step (diffuse_xyz + backbone_orientations)", lambda: (sb.diffuse_xyz(beta), sb.backbone_orientations())),
+    # where the time goes
+    ("  part: torch.empty (1 tensor, cuda)", lambda: torch.empty(B, N, 3, 3, device="cuda")),
+    ("  part: ops._stream(xg)", lambda: ops._stream(xg)),
+    ("  part: ctypes call of the K1 entry with B = 0 (no launch)", lambda: _K1(xg.data_ptr(), 0, d.data_ptr(), 0, 0, N, 15, 0, N, N, 0, _REF, 0)),
+    ("  part: ops._f32c + shape + _u8c", lambda: (ops._f32c(xg, "xyz"), xg.shape[:3], ops._u8c(mg, "m"))),
 ]
+from protstruc_amd import _lib
+_K1 = _lib.load().ps_pairwise_distance_cfg_f32
+_REF = _lib.k1_config_ref(0)
 for name, fn in rows:
     print(f"{name:50s} {per_call(fn):8.1f} us/call", flush=True)

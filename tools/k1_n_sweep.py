@@ -11,14 +11,17 @@ import torch
 from protstruc_amd import _lib, ops
 
 A = 15
-for kv in [v for v in sys.argv[1:] if "=" in v]:   # e.g. flat_cpw=2 flat=0
+for kv in [v for v in sys.argv[1:] if "=" in v]:   # e.g. flat_cpw=2 flat=0; A=5 sets the atom count
     k, v = kv.split("=")
-    _lib.set_tuning("k1_" + k, int(v))
+    if k == "A":
+        A = int(v)
+    else:
+        _lib.set_tuning("k1_" + k, int(v))
 lengths = [int(v) for v in sys.argv[1:] if "=" not in v] or [512, 511, 510, 508, 504, 500, 496, 437, 448, 256, 250, 128,
                                                              100, 64, 50, 33, 17]
 g = torch.Generator().manual_seed(0)
 for N in lengths:
-    B = int(os.environ["K1_B"]) if "K1_B" in os.environ else max(1, round(64 * 512 * 512 / (N * N)))
+    B = int(os.environ["K1_B"]) if "K1_B" in os.environ else max(1, round(64 * 512 * 512 * 225 / (N * N * A * A) * (0.5 if A != 15 else 1)))
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9)
     mask[:, :, :3] = True
@@ -37,7 +40,7 @@ for N in lengths:
     ts = sorted(a.elapsed_time(b) for a, b in ev)
     med = ts[len(ts) // 2]
     nbytes = B * N * N * A * A * 5
-    print(f"N={N:5d} B={B:5d}  med {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s",
+    print(f"A={A:3d} N={N:5d} B={B:5d}  med {med:7.3f} ms  {nbytes / med / 1e9:6.2f} TB/s  [{_lib.k1_plan(B, N, A)['kernel']}]",
           flush=True)
     del xyz, mask, dist, dmask
 print("autotune:", ops.k1_autotune_result())

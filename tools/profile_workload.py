@@ -6,6 +6,8 @@
     k1a     K1 at atom14 (N=256) and atom37 (N=128), ~8 GB of output each: default dispatch (fixed-A flat pattern
             kernel) and the any-A flat kernel (k1_flat=3)
     k1      the headline K1 launch (B=64, N=512, A=15)
+    k1s     K1 at the small atom counts, ~4 GB of output each: (A, N) = (5, 512), (5, 500), (5, 501), (3, 501), (1, 512),
+            (2, 512) through the default dispatch (row-phase kernel)
 Every kernel is launched `reps` times (default 10) after 2 warm-ups, nothing else runs on the GPU."""
 import os
 import sys
@@ -51,6 +53,15 @@ elif what == "k1a":
             _lib.set_tuning("k1_flat", flat)
             repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
         _lib.set_tuning("k1_flat", 1)
+        del xyz, mask, d, m
+elif what == "k1s":
+    for A, N in ((5, 512), (5, 500), (5, 501), (3, 501), (1, 512), (2, 512)):
+        B = max(1, int(4e9 / (N * N * A * A * 5)))
+        xyz, mask = synth(B, N, A)
+        d = torch.empty(B, N, N, A, A, device="cuda")
+        m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+        print("k1s", A, N, B, _lib.k1_plan(B, N, A), flush=True)
+        repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
         del xyz, mask, d, m
 elif what == "k1":
     xyz, mask = synth(64, 512)

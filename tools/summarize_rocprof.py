@@ -46,7 +46,7 @@ def pmc(d, out, skip=2):
     for f in find(d, "counter_collection.csv"):
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                k = short(r["Kernel_Name"])
+                k = short(r["Kernel_Name"]) + f" grid={r['Grid_Size']}"     # one entry per launch shape of a kernel
                 e = per.setdefault(k, {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
                                        "grid": int(r["Grid_Size"]), "wg": int(r["Workgroup_Size"]), "disp": {}})
                 dd = e["disp"].setdefault(int(r["Dispatch_Id"]), {"t": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
