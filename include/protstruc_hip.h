@@ -71,8 +71,6 @@ typedef struct ps_k1_config {
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int anya_fl_log2;     /* any-A flat kernel: log2(pairs per chunk), 0 = auto */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
-    int small_a;          /* atom counts 1..13 other than 4, 8: 0 (default) the row-phase kernel; 1 the round-2 paths (odd
-                             row-tile kernels + k1_mask_rows for A = 3, 5; flat / any-A / element kernels otherwise) */
     int experiment;       /* must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
                              run that writes WRONG values, +16 = fully unrolled group loop */
@@ -131,9 +129,9 @@ int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask,
  */
 typedef struct ps_k1_plan {
     int struct_size;            /* in: sizeof(ps_k1_plan) */
-    int n_launches;             /* 0 (empty input), 1, or 2 (distance plane + k1_mask_rows) */
-    char family[48];            /* "pattern" | "flat" | "flatA" | "flatS" | "rowtile" | "rowtile_odd" | "rowtile_odd_phased" |
-                                   "anyA" | "slot_decode" | "element" | ..., a second launch appended as " + mask_rows" */
+    int n_launches;             /* 0 (empty input) or 1 (every kernel writes both planes in one launch) */
+    char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" | "anyA" |
+                                   "element" (other atom counts); "empty"; a second launch would be appended with " + " */
     char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<128>" */
     unsigned n_workgroups;      /* grid of the first launch */
     unsigned lds_bytes;         /* static + dynamic LDS per workgroup of the first launch */

@@ -25,7 +25,11 @@
 // decode, row atoms in registers); any other N >= 16 takes the "flat pattern" kernel (the same fixed decode laid
 // over the flat pair axis, so rows need no alignment at all); the slot-decode kernel described above remains for
 // N < 16, unaligned planes and as the bit-identity cross-check in the tests.
-// Any A other than 15 takes the generic element-per-lane kernel at the bottom.
+//
+// Other atom counts: A = 4, 8 the row-tile kernel and A = 1, 2, 3, 5-7, 9-13 the row-phase kernel (column atoms
+// stationary in registers, any N); A = 14, 16, 24, 25, 27, 32, 37 the fixed-A flat pattern kernel; any other
+// 4 <= A <= 64 the any-A flat kernel; what is left (A > 64, unaligned planes) the element-per-lane kernel at the
+// bottom.  ps_k1_plan_f32 reports which one a given launch takes (the dispatcher below, run in record-only mode).
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
@@ -970,242 +974,6 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
     }
 }
 
-// ---- fixed-A flat pattern kernel for SMALL atom counts (A*A <= 128: backbone-only layouts, A = 3, 4, 5, 8) ----
-// Same flat pair axis, same pair-position LDS image, same fixed per-lane slot pattern as k1_pairdist_flatA, but a
-// 4-pair group is only A*A <= 128 float4 slots, so the 256 lanes take G = 256 / (A*A) groups per pass: lane t owns
-// slot t % (A*A) of group t / (A*A) of every pass (A = 4: 16 groups = 64 pairs per pass; A = 5: 10 groups, 250 lanes).
-// Lanes of one pass therefore sit in DIFFERENT groups, possibly in different rows, so the row bookkeeping that is
-// wave-uniform in the large-A kernel is per lane here: each lane walks its own (row, next row boundary), reloads its
-// four row atoms only when its row changes, and takes the element-wise path for a group that straddles a row change
-// or the edge of the active range.  The mask plane is handled the same way (G sixteen-pair groups per pass).
-template <int A>
-struct FlatS {
-    static_assert(A >= 1 && A <= 11, "small fixed-A flat kernel: A*A <= 128");
-    static constexpr int AA = A * A;
-    static constexpr int LPR = A <= 4 ? 4 : (A <= 8 ? 8 : 16);
-    static constexpr int RPP = 256 / LPR;
-    static constexpr int RS = A;                                          // float4 slots per staged residue
-    static constexpr int G = 256 / AA;                                    // groups per pass
-    static constexpr int FL_LOG2 = A <= 3 ? 9 : (A <= 5 ? 8 : 7);   // A/B-tested: A = 5 with 128 pairs 3.19 instead of 3.86 TB/s, A = 4 with 512 4.79 instead of 5.07, A = 3 with 512 2.76 instead of 2.33
-    static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
-    static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
-    static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;
-    static constexpr int NPD = (FLn / 4 + G - 1) / G;                     // distance passes per chunk
-    static constexpr int NPM = (FLn / 16 + G - 1) / G;                    // mask passes per chunk
-    static constexpr int MROWS = 2 + 14 / A;                              // mask rows a 16-byte slot can span
-};
-
-template <int A, bool EXACT, bool HASMASK>
-__global__ __launch_bounds__(256, 4) void k1_pairdist_flatS(const float* __restrict__ xyz,
-                                                           const uint8_t* __restrict__ amask,
-                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask,
-                                                           int B, int N, int out_rows, int out_row_origin,
-                                                           unsigned pbeg, unsigned pend, unsigned n_ranges,
-                                                           unsigned range_stride, unsigned cpr, int cpw,
-                                                           int xcd_remap, double rcpN_d, double rcpR_d) {
-    using G_ = FlatS<A>;
-    constexpr int AA = G_::AA, RSn = G_::RS, FLn = G_::FLn, FRn = G_::FRn, LPR = G_::LPR, RPP = G_::RPP, GP = G_::G;
-    constexpr int NPASS = FLn / RPP, RPASS = FRn / RPP;
-    __shared__ __attribute__((aligned(16))) float4 sxj[FLn * RSn];
-    __shared__ __attribute__((aligned(16))) float4 sxi[FRn * RSn];
-    __shared__ uint32_t smj[FLn], smi[FRn], smr[FLn];
-
-    const int tid = threadIdx.x;
-    unsigned w = blockIdx.x;
-    if (xcd_remap) {
-        const unsigned n = gridDim.x, x = w & 7u;
-        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
-    }
-    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
-    const int pl = tid / LPR, cl = tid % LPR;
-    constexpr uint32_t abits = (1u << A) - 1u;
-
-    const unsigned n_chunks = n_ranges * cpr;
-    for (int cc = 0; cc < cpw; ++cc) {
-        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
-        if (chunk >= n_chunks) break;  // uniform
-        if (cc) __syncthreads();
-        unsigned rg = 0, k = chunk;
-        if (n_ranges > 1) {
-            rg = chunk / cpr;
-            k = chunk - rg * cpr;
-        }
-        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
-        const unsigned P0 = ((rbeg >> G_::FL_LOG2) + k) << G_::FL_LOG2;
-        if (P0 >= rend) continue;  // uniform
-        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
-        const int hi = rend - P0 < (unsigned)FLn ? (int)(rend - P0) : FLn;
-        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
-        if (R0 * (unsigned long long)N > P0) --R0;
-        else if ((R0 + 1ull) * N <= P0) ++R0;
-        const int j_start = (int)(P0 - R0 * (unsigned)N);
-        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
-        if (b0 * (unsigned long long)out_rows > R0) --b0;
-        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
-        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
-        const int nr = (j_start + FLn - 1) / N + 1;  // rows the chunk touches (<= G_::NR)
-
-        // ---- stage ----
-        float vx[NPASS + RPASS], vy[NPASS + RPASS], vz[NPASS + RPASS];
-        unsigned vm[NPASS + RPASS];
-        bool va[NPASS + RPASS];
-        {
-            unsigned rl = udiv_rcp((unsigned)(j_start + pl), (unsigned)N, rcpN);
-            unsigned j = (unsigned)(j_start + pl) - rl * (unsigned)N;
-            const unsigned db = udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
-            unsigned il = il0 + rl - db * (unsigned)out_rows;
-            unsigned res0 = (b0 + db) * (unsigned)N;
-#pragma unroll
-            for (int pass = 0; pass < NPASS; ++pass) {
-                const int p = pass * RPP + pl;
-                va[pass] = (p >= lo) && (p < hi) && (cl < A);
-                const unsigned src = va[pass] ? (res0 + j) * A + cl : 0u;
-                vx[pass] = xyz[src * 3u + 0];
-                vy[pass] = xyz[src * 3u + 1];
-                vz[pass] = xyz[src * 3u + 2];
-                vm[pass] = HASMASK ? (unsigned)amask[src] : 1u;
-                j += RPP;                      // RPP (32 / 64) can exceed N (>= 16): several row changes per pass
-                while (j >= (unsigned)N) {
-                    j -= (unsigned)N;
-                    if (++il == (unsigned)out_rows) {
-                        il = 0;
-                        res0 += (unsigned)N;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int rp = 0; rp < RPASS; ++rp) {
-            const unsigned rr = (unsigned)(rp * RPP + pl);
-            const unsigned ilr = il0 + rr;
-            const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
-            const unsigned bb = b0 + db;
-            const unsigned i = ilr - db * (unsigned)out_rows + (unsigned)out_row_origin;
-            const int L = NPASS + rp;
-            va[L] = ((int)rr < nr) && (bb < (unsigned)B) && (cl < A);
-            const unsigned src = va[L] ? (bb * (unsigned)N + i) * A + cl : 0u;
-            vx[L] = xyz[src * 3u + 0];
-            vy[L] = xyz[src * 3u + 1];
-            vz[L] = xyz[src * 3u + 2];
-            vm[L] = HASMASK ? (unsigned)amask[src] : 1u;
-        }
-        constexpr int FIELDS = 64 / LPR;
-#pragma unroll
-        for (int pass = 0; pass < NPASS + RPASS; ++pass) {
-            const bool is_row = pass >= NPASS;
-            const int p = (is_row ? pass - NPASS : pass) * RPP + pl;
-            if (cl < RSn)
-                (is_row ? sxi : sxj)[p * RSn + cl] =
-                    va[pass] ? make_float4(vx[pass], vy[pass], vz[pass], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const unsigned long long bal = __ballot(va[pass] && vm[pass] != 0u);
-            if (cl == 0) (is_row ? smi : smj)[p] = (uint32_t)(bal >> (LPR * (pl % FIELDS))) & abits;
-        }
-        __syncthreads();
-        if (dmask)
-            for (int t = tid; t < FLn; t += 256) {   // (a loop: the chunk may be longer than the workgroup)
-                const unsigned rl = udiv_rcp((unsigned)(j_start + t), (unsigned)N, rcpN);
-                smr[t] = (t >= lo && t < hi) ? smi[rl] : 0u;
-            }
-        __syncthreads();
-        if (tid >= GP * AA) continue;   // idle in the sweeps; rejoins at the next chunk's barrier
-        const int gq = tid / AA;        // this lane's group inside a pass
-        const unsigned sl = (unsigned)(tid - gq * AA);   // its slot inside the group
-
-        if (dist) {
-            unsigned offj[4], ai[4], jo[4];
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const unsigned e = 4u * sl + kk;
-                jo[kk] = e / AA;
-                const unsigned r = e - jo[kk] * AA;
-                ai[kk] = r / A;
-                offj[kk] = ((unsigned)gq * 4u + jo[kk]) * RSn + (r - ai[kk] * A);
-            }
-            int rl = 0, nb = N - j_start, rl_loaded = -1;
-            float4 pi[4];
-#pragma unroll 1   // A/B against unroll 2 / 4 (tools/k1_ab_libs.py): equal for A = 4, 5; +3 % / +5 % for A = 8 / 3
-            for (int pass = 0; pass < G_::NPD; ++pass) {
-                const int g = pass * GP + gq;
-                const int p = 4 * g;
-                if (g >= FLn / 4 || p >= hi) break;   // later passes of this lane lie further on still
-                while (nb <= p) {
-                    ++rl;
-                    nb += N;
-                }
-                float* o = dist + (size_t)P0 * AA + (size_t)g * (4 * AA) + 4u * sl;
-                const float4* x = sxj + pass * (GP * 4 * RSn);
-                if (p >= lo && p + 4 <= min(nb, hi)) {   // the whole group inside one row and inside the active range
-                    if (rl != rl_loaded) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) pi[kk] = sxi[rl * RSn + ai[kk]];
-                        rl_loaded = rl;
-                    }
-                    const float4 q0 = lds_atom(x + offj[0]), q1 = lds_atom(x + offj[1]);
-                    const float4 q2 = lds_atom(x + offj[2]), q3 = lds_atom(x + offj[3]);
-                    uint4 v;
-                    v.x = __float_as_uint(dist_pp<EXACT>(pi[0], q0));
-                    v.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
-                    v.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
-                    v.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
-                    store16<false>(o, v);
-                } else if (p + 4 > lo) {   // straddles a row change or an edge of the active range: element-wise
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) {
-                        const int pp = p + (int)jo[kk];
-                        if (pp >= lo && pp < hi) {
-                            const int rk = rl + (pp >= nb ? 1 : 0);  // N >= 16: at most one row change per group
-                            o[kk] = dist_pp<EXACT>(sxi[rk * RSn + ai[kk]], x[offj[kk]]);
-                        }
-                    }
-                }
-            }
-        }
-
-        if (dmask) {
-            constexpr int MR = G_::MROWS;
-            const unsigned e0 = 16u * sl;   // byte inside a 16-pair group
-            const unsigned jo = e0 / AA, r = e0 - jo * AA;
-            const unsigned a = r / A, c = r - a * A;
-            unsigned prow[MR], arow[MR];
-            int sh[MR];
-#pragma unroll
-            for (int m = 0; m < MR; ++m) {
-                const unsigned am = a + m, dp = am / A;   // a 16-byte slot can reach into the second next pair when A = 3
-                prow[m] = min(jo + dp, 15u);              // rows with sh >= 16 contribute nothing (index clamped)
-                arow[m] = am - dp * A;
-                sh[m] = m * A - (int)c;
-            }
-#pragma unroll 1
-            for (int mp = 0; mp < G_::NPM; ++mp) {
-                const int mg = mp * GP + gq;
-                const int pg = 16 * mg;
-                if (mg >= FLn / 16 || pg >= hi) break;
-                if (pg + 16 <= lo) continue;
-                uint32_t win = 0;
-#pragma unroll
-                for (int m = 0; m < MR; ++m) {
-                    if (sh[m] < 16) {
-                        const uint32_t col = smj[pg + prow[m]], row = smr[pg + prow[m]];
-                        const uint32_t bits = ((row >> arow[m]) & 1u) ? col : 0u;
-                        win |= sh[m] <= 0 ? (bits >> (-sh[m])) : (bits << sh[m]);
-                    }
-                }
-                win &= 0xFFFFu;
-                uint8_t* og = dmask + (size_t)P0 * AA + (size_t)mg * (16 * AA) + e0;
-                if (pg >= lo && pg + 16 <= hi) {
-                    store16<false>(og, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
-                                                  spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
-                } else {
-                    for (unsigned t = 0; t < 16u; ++t) {
-                        const int pp = pg + (int)((e0 + t) / AA);
-                        if (pp >= lo && pp < hi) og[t] = (uint8_t)((win >> t) & 1u);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- row-tile kernel for the small even atom counts whose pair block is a whole number of 16-byte slots (A = 4, 8) ----
 // With A*A a multiple of 16 every pair's distance block (A*A floats) and mask block (A*A bytes) starts 16-byte aligned
 // for ANY N, and a float4 slot never leaves one row atom a and one column residue j.  So the lane -> (j, a, c..c+3)
@@ -1337,279 +1105,6 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
                 o += 2 * row_stride;
             }
         }
-    }
-}
-
-// ---- row-tile kernel for small ODD atom counts on aligned lengths (A = 3, 5 with N % 16 == 0) ----
-// The same column-stationary idea for pair blocks that are NOT a whole number of 16-byte slots: when N % 16 == 0 every
-// row run still starts 16-byte aligned in both planes, so slot s of a row tile decodes to the same four
-// (column residue, column atom) and the same four row atoms in every row.  The four column atoms stay in registers for
-// all rows; the (up to two distinct) row atoms of a slot are read per row.  A tile is JT column residues with JT a
-// multiple of 16 chosen so that a row run is just under 512 float4 slots (A = 5: 80 residues = 500 slots = 8 000 B;
-// A = 3: 224 residues = 504 slots).  A mask slot spans up to 2 + 14/A row atoms of up to three column residues, all of
-// the same row residue: the column masks stay in registers, the row's mask bits arrive once per row.
-// Lengths that are not a multiple of 16 keep the flat small-A kernel.
-template <int A>
-struct RowTileOdd {
-    static_assert(A == 3 || A == 5 || A == 7, "odd row-tile kernel");
-    static constexpr int AA = A * A;
-    static constexpr int JT = ((2048 / AA) / 16) * 16;   // column residues per tile: <= 512 dist slots, whole mask slots
-    static constexpr int DS = JT * AA / 4;               // float4 slots per row run (A = 5: 500, A = 3: 504)
-    static constexpr int SPL = (DS + 255) / 256;         // 2
-    static constexpr int MS = JT * AA / 16;              // 16-byte mask slots per row run (<= 128)
-    static constexpr int MR = 2 + 14 / A;                // row atoms a mask slot can span
-    static constexpr int MP = (16 + AA - 2) / AA + 1;    // column residues a mask slot can touch (A = 3: 3, A = 5: 2)
-};
-
-template <int A, bool EXACT, bool PHASED>
-__global__ __launch_bounds__(256) void k1_pairdist_rowtile_odd(const float* __restrict__ xyz,
-                                                               const uint8_t* __restrict__ amask,
-                                                               float* __restrict__ dist, uint8_t* __restrict__ dmask,
-                                                               int N, int row_begin, int row_end, int out_rows,
-                                                               int out_row_origin, int IR, int n_tiles, int n_ichunks,
-                                                               int xcd_remap) {
-    using T = RowTileOdd<A>;
-    constexpr int AA = T::AA, JT = T::JT;
-    static_assert(AA % 4 == 1, "the phase of a row is (R * N) mod 4 only because A*A = 1 (mod 4)");
-    extern __shared__ __attribute__((aligned(16))) char smem_ro[];
-    float4* sxj = reinterpret_cast<float4*>(smem_ro);           // [JT * A]
-    float4* sxi = sxj + JT * A;                                  // [IR * A]
-    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A);  // [JT + 2] column mask bits (two zero guards)
-    uint32_t* smi = smj + (JT + 2);                              // [IR]
-
-    const int tid = threadIdx.x;
-    unsigned w = blockIdx.x;
-    if (xcd_remap) w = (w & 7u) * (gridDim.x >> 3) + (w >> 3);
-    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
-    const int j0 = (int)tile * JT;
-    const int jn = min(JT, N - j0);   // whole tiles are a multiple of 16 residues; the last one is whatever is left
-    // Rows of this workgroup.  Aligned lengths (N % 4 == 0): IR consecutive rows, every row run starts 16-byte aligned.
-    // PHASED (any other N): the run of absolute row R = b * out_rows + (i - origin) starts ph = (R * N) mod 4 floats past
-    // a 16-byte boundary, so a workgroup takes rows of ONE residue class of R mod 4 (every fourth row): the same ph,
-    // hence the same per-lane pattern, in all of them.
-    int b, i0, in, ph = 0;
-    constexpr int STEP = PHASED ? 4 : 1;
-    if (PHASED) {
-        b = (int)(rest / (unsigned)(4 * n_ichunks));
-        const unsigned r2 = rest % (unsigned)(4 * n_ichunks);
-        // class fastest: the four classes of one block of 4 * IR rows run next to each other in time, so that block of
-        // the output is written as a whole (with the class as the outer index the distance plane of A = 5, N = 501 ran
-        // at 3.97 TB/s instead of 4.89)
-        const int rho = (int)(r2 & 3u), chunk = (int)(r2 >> 2);
-        const long long Rb = (long long)b * out_rows - out_row_origin;          // R = Rb + i, and Rb + row_begin >= 0
-        const int first = row_begin + (int)(((rho - (int)((Rb + row_begin) & 3)) + 4) & 3);
-        i0 = first + 4 * chunk * IR;
-        in = i0 < row_end ? min(IR, (row_end - i0 + 3) >> 2) : 0;
-        if (in <= 0) return;   // uniform: this class has fewer chunks than the largest one
-        ph = (int)((((Rb + i0) & 3) * (long long)(N & 3)) & 3);
-    } else {
-        b = (int)(rest / (unsigned)n_ichunks);
-        i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
-        in = min(IR, row_end - i0);
-    }
-
-    {
-        const float* gj = xyz + ((size_t)b * N + j0) * (A * 3);
-        float* lj = reinterpret_cast<float*>(sxj);
-        for (int f = tid; f < jn * (A * 3); f += 256) {
-            const int atom = f / 3, comp = f - atom * 3;
-            lj[atom * 4 + comp] = gj[f];
-        }
-        float* li = reinterpret_cast<float*>(sxi);
-        for (int f = tid; f < in * (A * 3); f += 256) {
-            const int il = f / (A * 3), g = f - il * (A * 3);
-            const int atom = g / 3, comp = g - atom * 3;
-            li[(il * A + atom) * 4 + comp] = xyz[((size_t)b * N + i0 + STEP * il) * (A * 3) + g];
-        }
-        for (int r = tid; r < JT + 2 + IR; r += 256) {
-            const bool is_j = r < JT + 2;
-            const int rl = is_j ? r : r - (JT + 2);
-            const bool valid = is_j ? (rl < jn) : (rl < in);
-            uint32_t bits = 0;
-            if (valid) {
-                if (amask) {
-                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 + rl : i0 + STEP * rl)) * A;
-#pragma unroll
-                    for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
-                } else {
-                    bits = (1u << A) - 1u;
-                }
-            }
-            (is_j ? smj : smi)[rl] = bits;
-        }
-    }
-    __syncthreads();
-
-    const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;
-    const size_t row_stride = (size_t)STEP * N * AA;
-    const int nel = jn * AA;                   // elements of this tile's run of one row
-    const int nslots = (nel + ph + 3) >> 2;    // 16-byte slots that touch it (aligned lengths: exactly nel / 4)
-
-    if (dist) {
-        // slot s covers tile elements t = 4 s - ph + kk; elements outside [0, nel) belong to the neighbouring tile or row
-        float4 q[T::SPL][4];
-        unsigned ai[T::SPL][4];
-        unsigned vm[T::SPL];   // bit kk: element kk of the slot is this tile's
-#pragma unroll
-        for (int u = 0; u < T::SPL; ++u) {
-            const int sl = tid + 256 * u;
-            vm[u] = 0;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int t = 4 * sl - ph + kk;
-                const bool ok = sl < nslots && t >= 0 && t < nel;
-                vm[u] |= (ok ? 1u : 0u) << kk;
-                const unsigned e = ok ? (unsigned)t : 0u;
-                const unsigned j = e / AA, r = e - j * AA;
-                ai[u][kk] = r / A;
-                q[u][kk] = sxj[j * A + (r - ai[u][kk] * A)];   // column atom of this element: registers for all rows
-            }
-        }
-        float* o = dist + row0 * AA + (4 * tid - ph);   // 16-byte aligned: the run starts ph floats past a boundary
-        for (int il = 0; il < in; ++il) {
-#pragma unroll
-            for (int u = 0; u < T::SPL; ++u) {
-                const float4* xi = sxi + il * A;
-                float v[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) v[kk] = dist_pp<EXACT>(xi[ai[u][kk]], q[u][kk]);
-                float* ou = o + 1024 * u;
-                if (vm[u] == 15u) {
-                    store16<false>(ou, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
-                                                  __float_as_uint(v[3])));
-                } else if (PHASED && vm[u]) {   // a slot shared with the neighbouring tile / row: element stores
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        if ((vm[u] >> kk) & 1u) ou[kk] = v[kk];
-                }
-            }
-            o += row_stride;
-        }
-    }
-
-    if (dmask && !PHASED) {
-        // (aligned lengths with N % 16 == 0 only; every other case writes the mask plane with k1_mask_rows)
-        // MS (<= 128) mask slots per row: lane t takes slot t % 128 of the rows with parity t / 128
-        const int ms = tid & 127, par = tid >> 7;
-        if (ms < jn * AA / 16) {
-            const unsigned e0 = 16u * (unsigned)ms;
-            const unsigned j = e0 / AA, r = e0 - j * AA;
-            const unsigned a = r / A, c = r - a * A;
-            uint32_t mjr[T::MR];      // column mask of the pair each spanned row atom belongs to
-            unsigned arow[T::MR];
-            int sh[T::MR];
-#pragma unroll
-            for (int m = 0; m < T::MR; ++m) {
-                const unsigned am = a + m, dp = am / A;
-                arow[m] = am - dp * A;
-                sh[m] = m * A - (int)c;
-                mjr[m] = smj[min(j + dp, (unsigned)(JT + 1))];   // guards hold 0; rows with sh >= 16 are not used
-            }
-            uint8_t* o = dmask + (row0 + (size_t)par * N) * AA + e0;
-            for (int il = par; il < in; il += 2) {
-                const uint32_t mi = smi[il];
-                uint32_t win = 0;
-#pragma unroll
-                for (int m = 0; m < T::MR; ++m) {
-                    if (sh[m] < 16) {
-                        const uint32_t bits = ((mi >> arow[m]) & 1u) ? mjr[m] : 0u;
-                        win |= sh[m] <= 0 ? (bits >> (-sh[m])) : (bits << sh[m]);
-                    }
-                }
-                win &= 0xFFFFu;
-                store16<false>(o, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
-                                             spread4((win >> 12) & 15u)));
-                o += 2 * row_stride;
-            }
-        }
-    }
-}
-
-// ---- mask plane of whole row blocks, any alignment (small odd atom counts on lengths with N % 4 == 0) ----
-// When N % 4 == 0 but N % 16 != 0 the DISTANCE plane's row runs are still 16-byte aligned (the row-tile kernel above
-// takes them) but the mask plane's are not.  The mask needs no coordinates and no per-lane pattern worth keeping in
-// registers, so it gets the simplest possible form: a workgroup owns IR consecutive rows of one structure -- one
-// contiguous byte range of the mask plane -- cuts it into absolute 16-byte slots, decodes each slot's first byte to
-// (row, column residue, a, c) at run time and ORs together the (up to 2 + 14/A) mask rows the slot spans, which may
-// continue into the next column residue and, at the end of a row, into the next row.  The ragged head and tail of the
-// range (< 16 bytes each) are written byte-wise.
-template <int A>
-__global__ __launch_bounds__(256) void k1_mask_rows(const uint8_t* __restrict__ amask, uint8_t* __restrict__ dmask,
-                                                    int N, int row_begin, int row_end, int out_rows,
-                                                    int out_row_origin, int IR, int n_ichunks) {
-    constexpr int AA = A * A, MR = 2 + 14 / A;
-    extern __shared__ uint32_t smask[];       // [N] column residues' mask bits | [IR + 1] row residues' (one zero guard)
-    uint32_t* smj = smask;
-    uint32_t* smi = smask + N;
-    const int tid = threadIdx.x;
-    const int b = (int)(blockIdx.x / (unsigned)n_ichunks);
-    const int i0 = row_begin + (int)(blockIdx.x % (unsigned)n_ichunks) * IR;
-    const int in = min(IR, row_end - i0);
-    for (int r = tid; r < N + IR + 1; r += 256) {
-        const bool is_j = r < N;
-        const int res = is_j ? r : i0 + (r - N);
-        uint32_t bits = 0;
-        if (is_j || (r - N) < in) {
-            if (amask) {
-                const uint8_t* m = amask + ((size_t)b * N + res) * A;
-#pragma unroll
-                for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
-            } else {
-                bits = (1u << A) - 1u;
-            }
-        }
-        smask[r] = bits;
-    }
-    __syncthreads();
-
-    const unsigned row_bytes = (unsigned)N * AA;
-    const size_t beg = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * row_bytes;   // first byte of the block
-    const unsigned len = (unsigned)in * row_bytes;
-    const unsigned head = (unsigned)((16u - (unsigned)(beg & 15u)) & 15u);                   // bytes before the first whole slot
-    const unsigned nslots = len > head ? (len - head) >> 4 : 0u;
-    const float rcp_row = 1.0f / (float)row_bytes;
-
-    // the 16 bits starting at byte offset `off` of the block (off < len); bits past the end of the block come back 0
-    auto window = [&](unsigned off) -> uint32_t {
-        unsigned il = udiv_rcp(off, row_bytes, rcp_row);
-        const unsigned r1 = off - il * row_bytes;
-        unsigned j = r1 / AA;
-        const unsigned r = r1 - j * AA;
-        const unsigned a = r / A, c = r - a * A;
-        uint32_t win = 0;
-#pragma unroll
-        for (int m = 0; m < MR; ++m) {
-            const int sh = m * A - (int)c;
-            if (sh < 16) {
-                const unsigned am = a + m, dp = am / A;
-                unsigned jj = j + dp, ii = il;
-                if (jj >= (unsigned)N) {   // past the last column residue: the next row's first pairs
-                    jj -= (unsigned)N;
-                    ++ii;
-                }
-                const uint32_t mi = smi[min(ii, (unsigned)IR)];   // the guard row holds 0
-                const uint32_t bits = ((mi >> (am - dp * A)) & 1u) ? smj[jj] : 0u;
-                win |= sh <= 0 ? (bits >> (-sh)) : (bits << sh);
-            }
-        }
-        return win & 0xFFFFu;
-    };
-
-    uint8_t* o = dmask + beg;
-    for (unsigned sl = tid; sl < nslots; sl += 256) {
-        const unsigned off = head + 16u * sl;
-        const uint32_t win = window(off);
-        store16<false>(o + off, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
-                                           spread4((win >> 12) & 15u)));
-    }
-    // ragged head [0, head) and tail [head + 16 nslots, len): one byte per lane
-    const unsigned tail0 = head + 16u * nslots;
-    if ((unsigned)tid < 32u) {
-        const bool is_tail = tid >= 16;
-        const unsigned t = (unsigned)tid & 15u;
-        const unsigned off = is_tail ? tail0 + t : t;
-        const bool live = is_tail ? off < len : (t < head && t < len);
-        if (live) o[off] = (uint8_t)(window(off) & 1u);
     }
 }
 
@@ -2175,74 +1670,11 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
 #undef PS_K1_FLAT2
 }
 
-// Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37,
-// the backbone-only layouts 3 (N, CA, C), 4 (+O), 5 (+CB) and 8 -- for 25 (the atom count of the reference's own
-// from_xyz test, tests/test_StructureBatch.py:11-21) and 16;
-// A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
-// kernel (cfg.flat == 4).  Other atom counts take the any-A flat kernel.
 // Row-tile kernel (A = 4, 8): any N, any row range; planes must be 16-byte aligned.
 bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int A) {
     if (g.variant != 0 || g.flat != 1) return false;   // flat = 3 / 4 force the flat kernels (cross-checks), 0 the simple one
     if (A != 4 && A != 8) return false;
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
-}
-
-// Odd small atom counts: only lengths with N % 16 == 0 (every row run 16-byte aligned in both planes).
-bool rowtile_odd_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
-    if (g.variant != 0 || g.flat != 1) return false;
-    // Any length.  N % 16 == 0: both planes aligned, one launch.  N % 4 == 0: the distance plane is aligned, the mask
-    // plane goes through k1_mask_rows.  Any other N: the distance rows are taken in four phase classes (PHASED) and the
-    // mask plane again goes through k1_mask_rows, whose LDS image holds all N column masks.
-    if ((A != 3 && A != 5) || N < 1 || N > 8192) return false;
-    if (g.small_a != 1) return false;   // since round 3 the row-phase kernel is the default for A = 3, 5; this is the A/B path
-    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
-}
-
-template <int A>
-int launch_mask_rows(const uint8_t* amask, uint8_t* dmask, int B, int N, int row_begin, int row_end, int out_rows,
-                     int out_row_origin, const K1Go& go) {
-    const int rows = row_end - row_begin;
-    // rows per workgroup: ~64 KB of mask bytes, at least 1, at most 32
-    int IR = (int)(65536 / ((long long)N * A * A));
-    IR = IR < 1 ? 1 : (IR > 32 ? 32 : IR);
-    if (IR > rows) IR = rows;
-    const int n_ichunks = (rows + IR - 1) / IR;
-    const unsigned long long n_wg = (unsigned long long)n_ichunks * B;
-    if (n_wg > 0x7FFFFFFFull || (unsigned long long)IR * N * A * A > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)(N + IR + 1) * sizeof(uint32_t);
-    return k1_go(go, "mask_rows", "k1_mask_rows", A, k1_mask_rows<A>, dim3((unsigned)n_wg), dim3(256), lds, amask, dmask,
-                 N, row_begin, row_end, out_rows, out_row_origin, IR, n_ichunks);
-}
-
-template <int A>
-int launch_rowtile_odd(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
-                       int N, int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
-    constexpr int JT = RowTileOdd<A>::JT;
-    const int rows = row_end - row_begin;
-    const bool phased = (N % 4 != 0);
-    const int class_rows = phased ? (rows + 3) / 4 : rows;     // rows of the largest phase class
-    const int IR = class_rows < 32 ? class_rows : 32;
-    const int n_tiles = (N + JT - 1) / JT, n_ichunks = (class_rows + IR - 1) / IR;
-    const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * (phased ? 4 : 1) * B;
-    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
-    const size_t lds = (size_t)(JT + IR) * A * sizeof(float4) + (size_t)(JT + 2 + IR) * sizeof(uint32_t);
-    // mask plane: inside the row-tile kernel when its row runs are 16-byte aligned too, else by k1_mask_rows
-    const bool mask_inside = (N % 16 == 0);
-    uint8_t* dm = mask_inside ? dmask : nullptr;
-    int rc = 0;
-    if (dist || dm) {
-#define PS_K1_RTO(EX_, PH_)                                                                                        \
-    k1_go(go, PH_ ? "rowtile_odd_phased" : "rowtile_odd", "k1_pairdist_rowtile_odd", A,                           \
-          k1_pairdist_rowtile_odd<A, EX_, PH_>, dim3((unsigned)n_wg), dim3(256), lds, xyz, amask, dist, dm, N,    \
-          row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_ichunks, remap)
-        if (phased) rc = g.exact_sqrt ? PS_K1_RTO(true, true) : PS_K1_RTO(false, true);
-        else rc = g.exact_sqrt ? PS_K1_RTO(true, false) : PS_K1_RTO(false, false);
-#undef PS_K1_RTO
-    }
-    if (rc == 0 && dmask && !mask_inside)
-        rc = launch_mask_rows<A>(amask, dmask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
-    return rc;
 }
 
 template <int A>
@@ -2269,7 +1701,7 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
 bool rowphase_has(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
 
 bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
-    if (g.variant != 0 || g.flat != 1 || g.small_a != 0 || !rowphase_has(A)) return false;
+    if (g.variant != 0 || g.flat != 1 || !rowphase_has(A)) return false;
     if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
@@ -2302,7 +1734,12 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
                  spt, n_ichunks, lpg_log2, remap);
 }
 
-bool flatA_has(int A) { return A == 3 || A == 4 || A == 5 || A == 8 || A == 14 || A == 15 || A == 16 || A == 25 || A == 37; }
+// Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37 -- for
+// 25 (the atom count of the reference's own from_xyz test, tests/test_StructureBatch.py:11-21), 16, 24, 27 and 32.
+// A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
+// kernels (cfg.flat == 4).  Atom counts up to 13 have the row-tile / row-phase kernels; every other count takes the
+// any-A flat kernel.
+bool flatA_has(int A) { return A == 14 || A == 15 || A == 16 || A == 24 || A == 25 || A == 27 || A == 32 || A == 37; }
 
 bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
     if (g.variant != 0 || g.flat == 0 || g.flat == 3 || !flatA_has(A)) return false;
@@ -2314,24 +1751,12 @@ bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int
     return true;
 }
 
-template <int A> struct FlatOf { typedef FlatA<A> type; };
-template <> struct FlatOf<3> { typedef FlatS<3> type; };
-template <> struct FlatOf<4> { typedef FlatS<4> type; };
-template <> struct FlatOf<5> { typedef FlatS<5> type; };
-template <> struct FlatOf<8> { typedef FlatS<8> type; };
-
-template <int A, bool EX, bool HM>
-auto flat_kernel_of() {
-    if constexpr (A * A <= 128) return &k1_pairdist_flatS<A, EX, HM>;
-    else return &k1_pairdist_flatA<A, EX, HM>;
-}
-
 template <int A>
 int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                  int out_rows, int out_row_origin, unsigned pbeg, unsigned pend, unsigned n_ranges,
                  unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
-    constexpr int L2 = FlatOf<A>::type::FL_LOG2, FLn = FlatOf<A>::type::FLn;
+    constexpr int L2 = FlatA<A>::FL_LOG2, FLn = FlatA<A>::FLn;
     const unsigned cpr = n_ranges == 1 ? ((pend + (FLn - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
     if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
@@ -2340,9 +1765,9 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_FLATA(EX_, HM_)                                                                                     \
-    k1_go(go, A * A <= 128 ? "flatS" : "flatA", A * A <= 128 ? "k1_pairdist_flatS" : "k1_pairdist_flatA", A,      \
-          flat_kernel_of<A, EX_, HM_>(), dim3(n_wg), dim3(256), 0, xyz, amask, dist, dmask, B, N, out_rows,       \
-          out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw, remap, rn, rr)
+    k1_go(go, "flatA", "k1_pairdist_flatA", A, k1_pairdist_flatA<A, EX_, HM_>, dim3(n_wg), dim3(256), 0, xyz,     \
+          amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw,  \
+          remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_FLATA(true, true) : PS_K1_FLATA(true, false);
     return amask ? PS_K1_FLATA(false, true) : PS_K1_FLATA(false, false);
 #undef PS_K1_FLATA
@@ -2399,7 +1824,6 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
     if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
     if (g.anya_fl_log2 != 0 && (g.anya_fl_log2 < 4 || g.anya_fl_log2 > 10)) return false;
-    if (g.small_a < 0 || g.small_a > 1) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
 #ifdef PS_EXPERIMENTS
     if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
@@ -2455,11 +1879,6 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         }
 #undef PS_K1_RP
     }
-    if (rowtile_odd_eligible(g, dist, dist_mask, N, A)) {
-        if (A == 3)
-            return launch_rowtile_odd<3>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
-        return launch_rowtile_odd<5>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
-    }
     if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure
         const bool whole = rows == out_rows;
@@ -2467,14 +1886,13 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         const unsigned r1 = whole ? (unsigned)((unsigned long long)B * out_rows * N) : r0 + (unsigned)rows * (unsigned)N;
         const unsigned nrg = whole ? 1u : (unsigned)B, stride = whole ? 0u : (unsigned)out_rows * (unsigned)N;
         switch (A) {
-            case 3: return launch_flatA<3>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 4: return launch_flatA<4>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 5: return launch_flatA<5>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 8: return launch_flatA<8>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 14: return launch_flatA<14>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 24: return launch_flatA<24>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 25: return launch_flatA<25>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 27: return launch_flatA<27>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
+            case 32: return launch_flatA<32>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 37: return launch_flatA<37>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             default: break;
         }

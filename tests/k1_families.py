@@ -16,12 +16,12 @@ FAMILY_SHAPES = [
     (2, 64, 15, None, False, {"k1_flat": 2, "k1_flat_fl_log2": 5}, "flat"),
     (2, 12, 15, None, False, {}, "slot_decode"),
     (2, 48, 15, None, False, {"k1_variant": 1}, "slot_decode"),
-    # fixed-A flat pattern kernels: A*A >= 129 (flatA) and A*A <= 128 (flatS, reached with k1_flat = 4)
+    # fixed-A flat pattern kernels (atom14, atom37, 16, 24, 25, 27, 32; A = 15 with k1_flat = 4 as the cross-check)
     (2, 40, 14, None, False, {}, "flatA"),
     (1, 20, 37, (3, 17), False, {}, "flatA"),
     (2, 33, 25, None, False, {}, "flatA"),
-    (2, 40, 5, None, False, {"k1_flat": 4}, "flatS"),
-    (2, 21, 8, (2, 19), True, {"k1_flat": 4}, "flatS"),
+    (2, 19, 27, (2, 19), True, {}, "flatA"),
+    (2, 35, 15, None, False, {"k1_flat": 4}, "flatA"),
     # row-tile kernels of A = 4, 8
     (2, 40, 4, None, False, {}, "rowtile"),
     (2, 33, 8, (1, 32), False, {}, "rowtile"),
@@ -32,19 +32,14 @@ FAMILY_SHAPES = [
     (2, 40, 7, None, False, {}, "rowphase"),
     (1, 30, 13, None, False, {}, "rowphase"),
     (2, 6, 3, None, False, {}, "rowphase"),
-    # the round-2 odd row-tile paths (k1_small_a = 1): aligned, N % 4 == 0 (+ k1_mask_rows), any other N (phased)
-    (2, 32, 5, None, False, {"k1_small_a": 1}, "rowtile_odd"),
-    (2, 20, 5, None, False, {"k1_small_a": 1}, "rowtile_odd + mask_rows"),
-    (2, 21, 3, (3, 18), False, {"k1_small_a": 1}, "rowtile_odd_phased + mask_rows"),
     # any-A flat kernel: atom counts without a fixed-A kernel
     (2, 40, 20, None, False, {}, "anyA"),
     (2, 17, 33, (0, 9), True, {}, "anyA"),
-    (2, 40, 7, None, False, {"k1_small_a": 1}, "anyA"),
+    (2, 40, 7, None, False, {"k1_flat": 3}, "anyA"),
     # element-per-lane kernel: A > 64, N < 16 without a row-phase kernel, or the simple variant
     (1, 8, 70, None, False, {}, "element"),
     (2, 10, 20, None, False, {}, "element"),
     (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
 ]
 
-ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "flatS", "rowtile", "rowphase", "rowtile_odd",
-                "rowtile_odd + mask_rows", "rowtile_odd_phased + mask_rows", "anyA", "element"}
+ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "anyA", "element"}

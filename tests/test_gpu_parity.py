@@ -265,7 +265,7 @@ def test_k1_flat_kernel_bit_identical_to_slot_decode(SB, exact):
     """The flat pattern kernel (any N >= 16) against the slot-decode kernel: same bits, nothing written outside the
     requested rows, for full / compact / in-place row ranges, chunks that span rows and structures, NaN atoms."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt", "k1_flat_fl_log2")
     saved = {k: _lib.get_tuning(k) for k in keys}
     SENT = 12345.0
     try:
@@ -281,9 +281,12 @@ def test_k1_flat_kernel_bit_identical_to_slot_decode(SB, exact):
             _lib.set_tuning("k1_variant", 0)
             _lib.set_tuning("k1_flat", 2)
             numel = ref_d.numel()
-            for cpw, nt in [(1, 0), (2, 0), (5, 1)]:
+            # (chunks per workgroup, non-temporal stores, log2 of pairs per chunk: 0 = the default 128-pair chunks;
+            # 4 / 5 / 6 = the 16 / 32 / 64-pair chunks of round 3's small-granule A/B)
+            for cpw, nt, fl in [(1, 0, 0), (2, 0, 0), (5, 1, 0), (1, 0, 4), (3, 0, 5), (2, 0, 6)]:
                 _lib.set_tuning("k1_flat_cpw", cpw)
                 _lib.set_tuning("k1_store_nt", nt)
+                _lib.set_tuning("k1_flat_fl_log2", fl)
                 # full matrix, written into the middle of a larger sentinel buffer (16-byte aligned offset)
                 pad = 64
                 bd = torch.full((numel + 2 * pad,), SENT, device="cuda")
@@ -328,12 +331,11 @@ def _same_floats(a, b):
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
     """The vectorised any-A flat kernel (k1_flat=3), the fixed-A flat pattern kernels (k1_flat=4), the row-tile kernels
-    of A = 4 / 8 and the row-phase kernel of the other small atom counts (k1_flat=1, the default dispatch), and the
-    round-2 odd row-tile paths (k1_small_a=1)
+    of A = 4 / 8 and the row-phase kernel of the other small atom counts (k1_flat=1, the default dispatch)
     against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
     at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt", "k1_small_a")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
     saved = {k: _lib.get_tuning(k) for k in keys}
     _lib.set_tuning("k1_exact_sqrt", exact)
     SENT = 12345.0
@@ -343,38 +345,36 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              # cross rows inside a 4-pair group, chunks that span several rows and structures, N = 16 (shortest)
              (2, 16, 14), (3, 300, 14), (2, 129, 14), (1, 16, 37), (2, 17, 37), (2, 130, 37), (2, 200, 15), (3, 19, 15),
              (2, 90, 16), (2, 70, 25), (1, 16, 25),
-             # small fixed-A kernel (several 4-pair groups per pass, per-lane row bookkeeping): N < pairs per pass
+             # backbone-only layouts at short and long lengths
              (3, 16, 3), (2, 100, 3), (4, 16, 4), (2, 17, 4), (3, 19, 5), (2, 300, 5), (2, 23, 8), (2, 200, 8),
              # row-tile kernel (A = 4, 8; the default dispatch): partial tiles, more rows than one workgroup takes
              (2, 129, 4), (1, 300, 4), (2, 33, 8), (1, 70, 8),
-             # odd row-tile kernel (A = 3, 5 with N % 16 == 0): one tile, partial last tile, several tiles
+             # A = 3, 5 with N % 16 == 0 (one alignment phase): one tile, partial last tile, several tiles
              (2, 32, 5), (1, 160, 5), (2, 240, 5), (2, 16, 3), (1, 224, 3), (1, 448, 3),
-             # N % 4 == 0 but not % 16: distances by the odd row-tile kernel, mask plane by k1_mask_rows
+             # N % 4 == 0 but not % 16
              (2, 20, 5), (3, 100, 5), (2, 500, 5), (2, 36, 3), (1, 228, 3), (3, 44, 3),
-             # any other N: distance rows in four alignment-phase classes (odd N, N % 4 == 2, tiny N)
+             # any other N: all four alignment phases (odd N), two (N % 4 == 2), tiny N
              (2, 17, 5), (3, 101, 5), (2, 499, 5), (2, 30, 5), (2, 19, 3), (1, 229, 3), (2, 6, 3), (2, 3, 5), (4, 2, 5),
              # row-phase kernel (round 3; A = 1, 2, 3, 5, 6, 7, 9..13): single atoms and pairs of atoms, every phase of
              # odd A, several tiles per row (A = 1: N > 2042; A = 5: N > 81; A = 13: N > 12), more rows than one
              # workgroup takes (N > 32), tiny N
              (2, 500, 1), (2, 501, 1), (2, 502, 1), (2, 503, 1), (1, 2100, 1), (3, 5, 1), (2, 1, 1), (1, 1030, 2),
              (2, 2, 2), (2, 99, 2), (2, 100, 6), (2, 37, 7), (2, 3, 7), (1, 64, 9), (2, 50, 10), (2, 33, 11), (1, 40, 12),
-             (2, 29, 13), (1, 90, 5), (1, 91, 5), (1, 93, 3), (1, 94, 3)]
+             (2, 29, 13), (1, 90, 5), (1, 91, 5), (1, 93, 3), (1, 94, 3),
+             # the fixed-A flat pattern kernels added in round 3
+             (2, 40, 24), (1, 33, 27), (1, 30, 32)]
 
     def paths(A):
-        """(k1_flat, k1_small_a) settings that reach a fast kernel for this atom count."""
-        if A in (4, 8):
-            return [(1, 0), (3, 0), (4, 0)]
-        if A in (3, 5):
-            return [(1, 0), (1, 1), (3, 0) if A == 5 else (4, 0), (4, 0)]
-        if A in (1, 2):
-            return [(1, 0)]
-        if A in (14, 15, 16, 25, 37):
-            return [(3, 0), (4, 0)]
-        return [(1, 0), (3, 0)] if A <= 13 else [(3, 0)]
+        """k1_flat settings that reach a fast kernel for this atom count (1: default dispatch = row-tile / row-phase
+        kernels; 3: any-A flat kernel; 4: fixed-A flat pattern kernel)."""
+        if A in (1, 2, 3):
+            return [1]
+        if A in (14, 15, 16, 24, 25, 27, 32, 37):
+            return [3, 4]
+        return [1, 3] if A <= 13 else [3]
 
     try:
-        for (B, N, A), (flat, small_a) in [(c, f) for c in cases for f in paths(c[2])]:
-            _lib.set_tuning("k1_small_a", small_a)
+        for (B, N, A), flat in [(c, f) for c in cases for f in paths(c[2])]:
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
@@ -395,8 +395,8 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
                 d = bd[pad:pad + numel].view(ref_d.shape)
                 m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
                 ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
-                assert _same_floats(d, ref_d), (B, N, A, cpw, flat, small_a)
-                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat, small_a)
+                assert _same_floats(d, ref_d), (B, N, A, cpw, flat)
+                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat)
                 assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
                 assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
                 d0, _ = ops.pairwise_distance(xg, None, want_mask=False)

@@ -2,9 +2,9 @@
 interleaved rounds (never compare across runs / boxes): flat=1 (the default dispatch: fixed-A flat pattern kernel
 for atom14 / atom37, any-A flat kernel otherwise), flat=3 (any-A flat kernel), flat=0 (element-per-lane kernel);
 plus the default dispatch with only the distance plane / only the mask plane.
-Round 3: "r2path" = the round-2 dispatch (k1_small_a=1: odd row-tile kernels + k1_mask_rows for A = 3, 5; flat / any-A /
-element kernels for the other small atom counts) next to the default (row-phase kernel), and "fill" = torch.fill_ on
-the same two buffers (which class of allocation the shape drew).
+Round 3: "fill" = torch.fill_ on the same two buffers (which class of allocation the shape drew).  (The "r2path" column
+of profiles/r03_k1_a_sweep_rowphase*.log was the round-2 dispatch -- odd row-tile kernels + k1_mask_rows, small fixed-A
+flat kernels -- timed next to the row-phase kernel that replaced them; those kernels were removed afterwards.)
 Arguments: key=value K1 tuning applied to every run (e.g. flat_cpw=2), `json=path` writes the table,
 `shapes=A:N,A:N,...` replaces the shape list."""
 import json, os, sys
@@ -28,7 +28,7 @@ for A, N in shapes:
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
     d = torch.empty(B, N, N, A, A, device="cuda"); m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-    variants = {"default": (1, True, True, 0), "r2path": (1, True, True, 1), "anyA": (3, True, True, 0),
+    variants = {"default": (1, True, True, 0), "anyA": (3, True, True, 0),
                 "element": (0, True, True, 0), "default_dist_only": (1, True, False, 0),
                 "default_mask_only": (1, False, True, 0), "fill": None}
     best = {k: float("inf") for k in variants}
@@ -40,7 +40,6 @@ for A, N in shapes:
             else:
                 flat, wd, wm, small_a = var
                 _lib.set_tuning("k1_flat", flat)
-                _lib.set_tuning("k1_small_a", small_a)
                 run = lambda: ops.pairwise_distance(xyz, mask, out_dist=d if wd else None, out_mask=m if wm else None,
                                                     want_dist=wd, want_mask=wm)
             for _ in range(2): run()
@@ -51,13 +50,12 @@ for A, N in shapes:
             e1.record(); torch.cuda.synchronize()
             best[name] = min(best[name], e0.elapsed_time(e1) / 5)
     _lib.set_tuning("k1_flat", 1)
-    _lib.set_tuning("k1_small_a", 0)
-    nbytes = {"default": 5, "r2path": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
-    row = {"A": A, "N": N, "B": B, "kernel": _lib.k1_plan(B, N, A)["kernel"], "r2_kernel": _lib.k1_plan(B, N, A, small_a=1)["kernel"], **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
+    nbytes = {"default": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
+    row = {"A": A, "N": N, "B": B, "kernel": _lib.k1_plan(B, N, A)["kernel"], **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
                                      for k, v in best.items()}}
     rows.append(row)
     print(f"A={A:3d} N={N:4d} B={B:5d} " + "  ".join(f"{k} {v['TBps']:5.2f}" for k, v in row.items() if isinstance(v, dict))
-          + f"  [{row['kernel']} | r2: {row['r2_kernel']}]", flush=True)
+          + f"  [{row['kernel']}]", flush=True)
     del xyz, mask, d, m
 if out_json:
     with open(out_json, "w") as f: json.dump(rows, f, indent=1)
