@@ -426,6 +426,11 @@ def main():
     out_m.fill_(False)
     starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # torch creates the underlying HIP event at the first record(): do that here, outside the timed region, so that the
+    # timed loop allocates nothing (a first-use allocation of timing events in front of the FIRST launch leaves the GPU
+    # idle for its duration -- seen once as 11 ms of wall clock that no kernel accounted for)
+    for ev in starts + ends:
+        ev.record()
 
     torch.cuda.synchronize(dev)
     if dist:
@@ -440,7 +445,8 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
+    per_step_ms = [s.elapsed_time(e) for s, e in zip(starts, ends)]
+    kernel_ms = sum(per_step_ms) / args.steps
     per_rank_kernel_ms = [kernel_ms]
     if dist:   # every rank's own figure: the spread between ranks is the fast / slow output-buffer lottery
         per_rank_kernel_ms = [None] * world
@@ -501,6 +507,8 @@ def main():
                                       "buffers' shape, alignment and this device's configuration",
                      "kernel_workgroups": plan["n_workgroups"], "kernel_lds_bytes_per_workgroup": plan["lds_bytes"],
                      "kernel_ms": kernel_ms_max,
+                     "kernel_ms_min_max_this_rank": [min(per_step_ms), max(per_step_ms)],
+                     "wall_minus_kernel_ms_per_step": elapsed / args.steps * 1e3 - kernel_ms_max,
                      "algorithmic_bytes_per_launch": B * N_RES * N_RES * BYTES_PER_PAIR,
                      "buffer_fill_GBps": fill_GBps_min, "frac_of_buffer_fill": achieved / fill_GBps_min,
                      "buffer_fill_what": "torch.fill_ on the two timed output buffers, HIP events, mean of 5 after one "

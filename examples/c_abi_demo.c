@@ -45,6 +45,17 @@ int main(void) {
 
     if (ps_abi_version() != PS_ABI_VERSION) { fprintf(stderr, "ABI %d != header %d\n", ps_abi_version(), PS_ABI_VERSION); return 4; }
     if (ps_has_experiments()) { fprintf(stderr, "experiments build\n"); return 4; }
+    {   /* which kernel will the launch below take?  A pure host query: the library's own dispatcher in record-only mode */
+        ps_k1_plan plan;
+        memset(&plan, 0, sizeof plan);
+        plan.struct_size = (int)sizeof plan;
+        PS(ps_k1_plan_f32(B, N, A, 0, N, N, 0, 0, 0, 1, NULL, &plan));
+        printf("K1 plan for B=%d N=%d A=%d: %s (%s), %u workgroups, %d launch(es)\n", B, N, A, plan.kernel, plan.family,
+               plan.n_workgroups, plan.n_launches);
+        if (plan.n_launches != 1 || plan.n_workgroups == 0 || !plan.kernel[0]) return 6;
+        plan.struct_size = 8;   /* a caller built against another header is refused */
+        if (ps_k1_plan_f32(B, N, A, 0, N, N, 0, 0, 0, 1, NULL, &plan) != 1) return 6;
+    }
 
     float *d_xyz, *d_dist, *d_rot, *d_trans;
     uint8_t *d_mask, *d_dmask;

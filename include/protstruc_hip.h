@@ -271,12 +271,15 @@ int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, in
  * K1's dist), omega = dihedral(CA_i,CB_i,CA_j,CB_j), theta =
  * dihedral(N_i,CA_i,CB_i,CB_j), phi = angle(CA_i,CB_i,CB_j), and the three
  * (B,N,N) u8 mask planes.  atom_mask may be NULL (all present).  Needs A >= 5.
+ * exact_sqrt: the square root of the three distance planes, as ps_k1_config.exact_sqrt -- 0: hardware v_sqrt_f32
+ * (K1's default: the planes are then bit-identical to the slices of a default K1 launch), 1: correctly rounded
+ * (bit-identical to K1 with exact_sqrt = 1).
  */
 int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
                                   float* d_ca, float* d_cb, float* d_no,
                                   float* omega, float* theta, float* phi,
                                   uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask,
-                                  int B, int N, int A, void* stream);
+                                  int B, int N, int A, int exact_sqrt, void* stream);
 
 /*
  * Rigid-body ops.  ps_rigid_f32 replaces StructureBatch.translate,

@@ -56,7 +56,7 @@ SIGNATURES = {
     "ps_diffusion_trajectory_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_f32p,
                                              _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_inter_residue_geometry_f32": (_c_int, [_c_f32p, _c_u8p] + [_c_f32p] * 6 + [_c_u8p] * 3 + [_c_int, _c_int, _c_int,
-                                                                                                  _c_stream]),
+                                                                                                  _c_int, _c_stream]),
     "ps_rigid_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_center_of_mass_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_frames_to_backbone_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),

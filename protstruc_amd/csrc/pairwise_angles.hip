@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
 // Fused trRosetta featuriser (reference protstruc.py:790-817): the three atom-pair planes of K1 that
 // inter_residue_geometry slices out (CA-CA, CB-CB, N-O), their masks, and the three K3 features, in
 // one sweep -- 27 bytes written per residue pair instead of 1125.  Same lane layout as K3.
+template <bool EXACT>
 __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
@@ -111,9 +112,9 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         }
     };
     auto row_planes = [&](size_t o, f3 n_i, f3 ca_i, f3 cb_i, uint8_t mi_n, uint8_t mi_ca, uint8_t mi_cb) {
-        d_ca[o] = dist3(ca_i, ca_j);
-        d_cb[o] = dist3(cb_i, cb_j);
-        d_no[o] = dist3(n_i, o_j);
+        d_ca[o] = dist3_t<EXACT>(ca_i, ca_j);
+        d_cb[o] = dist3_t<EXACT>(cb_i, cb_j);
+        d_no[o] = dist3_t<EXACT>(n_i, o_j);
         m_ca[o] = mi_ca & mj_ca;
         m_cb[o] = mi_cb & mj_cb;
         m_no[o] = mi_n & mj_o;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         const size_t o = ((size_t)b * N + i) * N + j;
         const f3v cav = mk3v(ca0, ca1), cbv = mk3v(cb0, cb1), nv = mk3v(n0, n1);
         const f3v cajv = mk3v(ca_j, ca_j), cbjv = mk3v(cb_j, cb_j), ojv = mk3v(o_j, o_j);
-        const f32x2 dca = dist3v(cav, cajv), dcb = dist3v(cbv, cbjv), dno = dist3v(nv, ojv);
+        const f32x2 dca = dist3v_t<EXACT>(cav, cajv), dcb = dist3v_t<EXACT>(cbv, cbjv), dno = dist3v_t<EXACT>(nv, ojv);
         const f32x2 ph = angle3v(cav, cbv, cbjv);
         const f32x2 om = dihedral4v_k3(cav, cbv, cajv, cbjv);   // as coded at protstruc.py:811
         const f32x2 th = dihedral4v_k3(nv, cav, cbv, cbjv);
@@ -206,16 +207,20 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
 extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb,
                                              float* d_no, float* omega, float* theta, float* phi, uint8_t* d_ca_mask,
                                              uint8_t* d_cb_mask, uint8_t* d_no_mask, int B, int N, int A,
-                                             void* stream) {
+                                             int exact_sqrt, void* stream) {
     if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
         return (int)hipErrorInvalidValue;
-    if (B < 0 || N < 0 || A < 5) return (int)hipErrorInvalidValue;
+    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1)) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
     const int IR = 16;
     const int n_tiles = (N + 255) / 256, n_chunks = (N + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    return ps_launch(k3_inter_residue_geometry, dim3((unsigned)n_wg), dim3(256), 0,
+    if (exact_sqrt)
+        return ps_launch(k3_inter_residue_geometry<true>, dim3((unsigned)n_wg), dim3(256), 0,
+                         reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
+                         d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
+    return ps_launch(k3_inter_residue_geometry<false>, dim3((unsigned)n_wg), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
                      d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
 }

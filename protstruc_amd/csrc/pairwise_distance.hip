@@ -736,7 +736,8 @@ struct FlatA {
             if ((4u * m) % (unsigned)A == 1u) return m;
         return 1u;
     }
-    typedef typename std::conditional<(A > 32), unsigned long long, uint32_t>::type mask_t;
+    // (A = 32 needs the wide word too: the all-atoms mask is (1 << A) - 1)
+    typedef typename std::conditional<(A >= 32), unsigned long long, uint32_t>::type mask_t;
 };
 
 template <int A>

@@ -79,6 +79,15 @@ __device__ __forceinline__ float dist3(f3 a, f3 b) {
     return sqrt_rn_mk((sx + sy) + sz);
 }
 
+// the same with K1's choice of square root (ps_k1_config.exact_sqrt): hardware v_sqrt_f32 or correctly rounded
+template <bool EXACT>
+__device__ __forceinline__ float dist3_t(f3 a, f3 b) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    const float x = (sx + sy) + sz;
+    return EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
+}
+
 // x.norm(dim=-1) (geometry.py:29-31); correctly rounded sqrt in half the instructions of the library routine
 // (identical result unless the squared norm is subnormal, i.e. |a| < 1e-19)
 __device__ __forceinline__ float norm3(f3 a) { return sqrt_rn_mk(dot3(a, a)); }
@@ -169,8 +178,9 @@ __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
 // pi); what is dropped are six per-element compare / select instructions that only matter for infinite arguments:
 //   * max(|x|, |y|) is clamped below at FLT_MIN inside the same v_max3_f32, which makes 0 / 0 come out as 0 without the
 //     separate (mx == 0) select;
-//   * NaN is re-injected with two fused multiply-adds by zero (v_min / v_max drop NaNs) instead of two compares, an or
-//     and a select;
+//   * NaN: v_min / v_max drop NaNs, so a NaN x is re-injected with one fused multiply-add by zero (instead of two
+//     compares, an or and a select).  y needs none: in dihedral4_k3 y = n1 . (c - d) is NaN only if a coordinate is, and
+//     then x = (n1 . n2) * rsq is NaN as well; x alone is NaN when b1 = 0 (0 * inf), the reference's 0 / 0;
 //   * atan2(+-inf, +-inf) and atan2(finite, +-inf) come out NaN instead of multiples of pi / 4.  x and y are dot
 //     products of cross products of coordinate differences: they overflow only for coordinates beyond 4e9 A.
 __device__ __forceinline__ float atan2_k3(float y, float x) {
@@ -190,7 +200,7 @@ __device__ __forceinline__ float atan2_k3(float y, float x) {
     float r = a * p;
     r = (ay > ax) ? (1.5707963267948966f - r) : r;
     r = (__float_as_uint(x) >> 31) ? (3.141592653589793f - r) : r;
-    r = __builtin_fmaf(x, 0.0f, __builtin_fmaf(y, 0.0f, r));   // r >= +0 here: adding +-0 leaves it, NaN / inf poison it
+    r = __builtin_fmaf(x, 0.0f, r);   // r >= +0 here: adding +-0 leaves it, a NaN (or infinite) x poisons it
     return copysignf(r, y);
 }
 
@@ -298,7 +308,7 @@ __device__ __forceinline__ f32x2 atan2_k3_v(f32x2 y, f32x2 x) {
     const f32x2 rh = k2(3.141592653589793f) - r;
     r.x = (__float_as_uint(x.x) >> 31) ? rh.x : r.x;
     r.y = (__float_as_uint(x.y) >> 31) ? rh.y : r.y;
-    r = __builtin_elementwise_fma(x, k2(0.0f), __builtin_elementwise_fma(y, k2(0.0f), r));
+    r = __builtin_elementwise_fma(x, k2(0.0f), r);
     return f32x2{copysignf(r.x, y.x), copysignf(r.y, y.y)};
 }
 
@@ -355,6 +365,15 @@ __device__ __forceinline__ f32x2 dist3v(f3v a, f3v b) {
 // square roots and an IEEE divide (3 instructions instead of ~29; the relative rounding error of the cosine is ~1.5 ulp
 // either way) -- and acos_ps above.  A zero-length arm (the diagonal of pairwise_planar_angles) is 0 * rsq(0) = 0 * inf
 // = NaN like the reference's 0 / 0; the squared lengths multiply without overflow up to 1e9 A arms.
+template <bool EXACT>
+__device__ __forceinline__ f32x2 dist3v_t(f3v a, f3v b) {
+    const f32x2 dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    const f32x2 sx = dx * dx, sy = dy * dy, sz = dz * dz;
+    const f32x2 x = (sx + sy) + sz;
+    if (EXACT) return sqrt_rn_mk_v(x);
+    return f32x2{__builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y)};
+}
+
 __device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
     const f3v ba = sub3v(a, b), bc = sub3v(c, b);
     const f32x2 num = dot3v(ba, bc);

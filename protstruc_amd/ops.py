@@ -404,7 +404,8 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
 
 
 def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None):
-    """Fused featuriser: dict of six (B,N,N) fp32 planes and three (B,N,N) bool planes."""
+    """Fused featuriser: dict of six (B,N,N) fp32 planes and three (B,N,N) bool planes.  The distance planes use the
+    device's K1 square-root mode (``set_exact_sqrt``), so they equal the slices of ``pairwise_distance`` bit for bit."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     if A < 5:
@@ -421,7 +422,8 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
         if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
             fp, kp, plane = f.data_ptr(), k.data_ptr(), B * N * N     # plane addresses by arithmetic, not by 9 views
             rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * plane * i for i in range(6)],
-                                                           *[kp + plane * i for i in range(3)], B, N, A, _stream(xyz))
+                                                           *[kp + plane * i for i in range(3)], B, N, A,
+                                                           _lib.get_tuning("k1_exact_sqrt", dev), _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
     out = dict(zip(fkeys, f.unbind(0)))
     out.update(zip(mkeys, k.unbind(0)))

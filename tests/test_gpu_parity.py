@@ -1399,24 +1399,28 @@ def test_inter_residue_geometry_golden(SB):
 
 
 def test_inter_residue_geometry_matches_unfused_kernels(SB):
-    """The fused featuriser must equal the K1 slices (K1 in its correctly rounded mode, which is what the featuriser
-    always uses; within 1 ulp of K1's default hardware-sqrt mode) and the K3 calls it replaces, bit for bit."""
+    """The fused featuriser must equal the K1 slices -- in BOTH square-root modes of the device (it takes the mode K1
+    takes: the hardware square root by default, the correctly rounded one after set_exact_sqrt(True)), the two modes
+    within 1 ulp of each other -- and the K3 calls it replaces, bit for bit."""
     from protstruc_amd import ops
     xyz, mask = synth(77, 3, 100)
     sb = SB.from_xyz(xyz, mask)
-    geo = sb.inter_residue_geometry()
     was = ops.get_exact_sqrt()
+    geos = {}
     try:
-        ops.set_exact_sqrt(True)
-        d, m = sb.pairwise_distance_matrix()
-        ops.set_exact_sqrt(False)
-        d_hw, _ = sb.pairwise_distance_matrix()
+        for exact in (False, True):
+            ops.set_exact_sqrt(exact)
+            geos[exact] = sb.inter_residue_geometry()
+            d, m = sb.pairwise_distance_matrix()
+            for key, (a, c) in {"d_ca": (1, 1), "d_cb": (4, 4), "d_no": (0, 3)}.items():
+                assert torch.equal(geos[exact][key], d[:, :, :, a, c]), (key, exact)
+                assert torch.equal(geos[exact][key + "_mask"], m[:, :, :, a, c]), (key, exact)
     finally:
         ops.set_exact_sqrt(was)
-    for key, (a, c) in {"d_ca": (1, 1), "d_cb": (4, 4), "d_no": (0, 3)}.items():
-        assert torch.equal(geo[key], d[:, :, :, a, c]) and torch.equal(geo[key + "_mask"], m[:, :, :, a, c])
-        ulps = (geo[key].view(torch.int32) - d_hw[:, :, :, a, c].contiguous().view(torch.int32)).abs()
+    for key in ("d_ca", "d_cb", "d_no"):
+        ulps = (geos[True][key].view(torch.int32) - geos[False][key].view(torch.int32)).abs()
         assert int(ulps.max()) <= 1
+    geo = geos[bool(was)]
 
     def same(x, y):
         return torch.equal(x.isnan(), y.isnan()) and torch.equal(x.nan_to_num(0), y.nan_to_num(0))

@@ -6,7 +6,7 @@ import sys
 import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from protstruc_amd import StructureBatch, ops
+from protstruc_amd import StructureBatch, _lib, ops
 
 g = torch.Generator().manual_seed(0)
 B, N = 1, 64
@@ -49,8 +49,14 @@ rows = [
     ("  part: ops._stream(xg)", lambda: ops._stream(xg)),
     ("  part: ctypes call of the K1 entry with B = 0 (no launch)", lambda: _K1(xg.data_ptr(), 0, d.data_ptr(), 0, 0, N, 15, 0, N, N, 0, _REF, 0)),
     ("  part: ops._f32c + shape + _u8c", lambda: (ops._f32c(xg, "xyz"), xg.shape[:3], ops._u8c(mg, "m"))),
+    # the floor of any launch from Python: the C entry point called directly with prebuilt arguments (ctypes marshalling
+    # + hipLaunchKernel), no validation, no allocation
+    ("  floor: bare ctypes launch of ps_frames_f32 (K4)", lambda: _K4(_xp, _rp, None, B, N, 15, 0, 1, 2, 1, 0)),
+    ("  floor: bare ctypes launch of the K1 entry", lambda: _K1(_xp, _mp, _dp, _mmp, B, N, 15, 0, N, N, 0, _REF, 0)),
 ]
-from protstruc_amd import _lib
+_K4 = _lib.load().ps_frames_f32
+_rot = torch.empty(B, N, 3, 3, device="cuda")
+_xp, _rp, _mp, _dp, _mmp = xg.data_ptr(), _rot.data_ptr(), mg.data_ptr(), d.data_ptr(), m.data_ptr()
 _K1 = _lib.load().ps_pairwise_distance_cfg_f32
 _REF = _lib.k1_config_ref(0)
 for name, fn in rows:
