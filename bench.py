@@ -256,7 +256,13 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
     if done:
         res["allgather_best_ms"], res["allgather_best_impl"] = min(done)
         res["allgather_best_ingress_GBps_per_rank"] = ingress / (res["allgather_best_ms"] * 1e-3) / 1e9
-    e2e = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather=True, out_dist=out_d, out_mask=out_m)
+    if not done:
+        raise RuntimeError("no all-gather implementation completed: " +
+                           "; ".join(f"{k}: {v}" for k, v in res.items() if k.endswith("_error")))
+    # end to end with the implementation that worked best (normally the native one)
+    e2e = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather=True, impl=res["allgather_best_impl"],
+                                                     out_dist=out_d, out_mask=out_m)
+    res["end_to_end_impl"] = res["allgather_best_impl"]
     res["end_to_end_ms"] = timed(e2e, steps)
     res["end_to_end_pairs_per_s"] = pairs / (res["end_to_end_ms"] * 1e-3)
     # after the last gather every rank must hold the whole matrix: check blocks from every rank's rows + checksum,
@@ -567,11 +573,13 @@ def main():
             result["config4_end_to_end_ms"] = rs["end_to_end_ms"]
             result["config4_end_to_end_pairs_per_s"] = rs["end_to_end_pairs_per_s"]
             result["config4_full_matrix_on_one_gpu_ms"] = rs["full_matrix_recomputed_per_rank_ms"]
-            errs = [f"{k}: {v}" for k, v in rs.items() if k.endswith("_error")]
+            # one of the two gather implementations failing while the other completed and the gathered matrix checks out
+            # is reported (loudly, top level) but does not void the run; a failed check does
+            partial = [f"{k}: {v}" for k, v in rs.items() if k.endswith("_error")]
+            if partial:
+                result["rowshard_warning"] = "; ".join(partial)
             if rs.get("check_after_gather") != "ok":
-                errs.append(f"check_after_gather: {rs.get('check_after_gather')}")
-            if errs:
-                result["rowshard_error"] = "; ".join(errs)
+                result["rowshard_error"] = f"check_after_gather: {rs.get('check_after_gather')}"
                 exit_code = 4
         except Exception as exc:  # noqa: BLE001 -- the main measurement is still printed, the failure is not hidden
             result["rowshard_allgather"] = None
