@@ -17,7 +17,7 @@ class K1Config(ctypes.Structure):
     """``ps_k1_config`` of include/protstruc_hip.h, field for field."""
     _fields_ = [(name, ctypes.c_int) for name in (
         "struct_size", "exact_sqrt", "variant", "flat", "rows_per_block", "lds_pad_kb", "flat_cpw",
-        "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "anya_fl_log2", "flat_fl_log2", "experiment")]
+        "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "anya_fl_log2", "flat_fl_log2", "rowphase", "experiment")]
 
 
 class K1Plan(ctypes.Structure):
@@ -140,7 +140,7 @@ _K1_KEYS = {   # tuning key -> (struct field, lowest, highest)
     "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", 0, 120),
     "k1_flat_cpw": ("flat_cpw", 1, 64), "k1_flat_lds_pad_kb": ("flat_lds_pad_kb", 0, 100),
     "k1_jt": ("jt", 0, 128), "k1_xcd_remap": ("xcd_remap", 0, 1), "k1_store_nt": ("store_nt", 0, 1),
-    "k1_anya_fl_log2": ("anya_fl_log2", 0, 10), "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_experiment": ("experiment", 0, 31),
+    "k1_anya_fl_log2": ("anya_fl_log2", 0, 10), "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 2), "k1_experiment": ("experiment", 0, 31),
 }
 _k1_lock = threading.RLock()
 _k1_table = {}   # device index -> {field: value}

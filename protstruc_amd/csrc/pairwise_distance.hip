@@ -1126,39 +1126,44 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
 //   * the four row atoms of a slot's elements are LDS reads (broadcasts: many lanes read the same few atoms) whose
 //     fourth component carries the atom's mask bit; for A = 1 there is a single row atom, read once per row;
 //   * everything per row (phase, row pointer, LDS row address) is wave-uniform and rides in SGPRs.
-template <int A>
+// ACT > 0: the atom count is the compile-time constant ACT (the small counts: index decode with constant divisors);
+// ACT = 0 / -1: a RUN-TIME even / odd atom count up to 64 (same kernel; the decode -- once per workgroup -- divides at run
+// time, the column mask words are 64 bits wide).  Only the parity of A decides the code shape (one phase or four).
+template <int ACT>
 struct RowPhase {
-    static_assert(A >= 1 && A <= 13, "row-phase kernel: small atom counts");
-    static constexpr int AA = A * A;
-    static constexpr bool PHASED = (AA % 4) != 0;      // odd A (A*A = 1 mod 4); even A: every row run is 16-byte aligned
+    static_assert(ACT >= -1 && ACT <= 31, "row-phase kernel: compile-time atom counts up to 31");
+    static constexpr bool PHASED = ACT > 0 ? ((ACT * ACT) % 4 != 0) : (ACT == -1);   // odd A: A*A = 1 (mod 4)
     static constexpr int W = PHASED ? 7 : 4;           // elements per slot whose column atoms a lane keeps
     static constexpr int W0 = PHASED ? 3 : 0;          // window element of row element 4 s
     static constexpr int SPL = 2;                      // slots per lane per row
     static constexpr int TS = 256 * SPL;               // slots per tile-row at most (8 KB of distances)
-    static constexpr int MAXRES = (4 * TS + 2) / AA + 2;   // column residues a tile's elements can touch
+    typedef typename std::conditional<(ACT > 0), uint32_t, unsigned long long>::type bits_t;   // A mask bits of a residue
 };
+
+// column residues a tile's elements can touch (host and device use the same formula for the LDS carve)
+__host__ __device__ inline int rowphase_maxres(int A) { return (4 * 512 + 2) / (A * A) + 2; }
 
 // One slot of one row.  `xi_row`: LDS address of the row residue's atoms (uniform over the wave); od / om point at the slot
 // (float / byte offset 4 s - ph of the row run); PH = the row's phase.  The row atom of every element arrives as one
 // ds_read_b128 whose fourth component is that atom's mask bit (0 / 1 as an integer), so the mask costs no second lookup.
-template <int A, bool EXACT, int PH>
+template <int ACT, bool EXACT, int PH>
 __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, const float (&col)[7][3],
                                               const uint32_t (&aoff)[7], uint32_t cm, uint32_t valid,
                                               float* __restrict__ od_, uint8_t* __restrict__ om_, bool wd, bool wm) {
     // wd / wm: whether the distance / mask plane is produced (uniform); the pointers are only meaningful when set
     float* od = wd ? od_ : nullptr;
     uint8_t* om = wm ? om_ : nullptr;
-    using T = RowPhase<A>;
+    using T = RowPhase<ACT>;
     constexpr int WO = T::W0 - PH;                     // window element of the slot's first element
     const uint32_t vm = (valid >> WO) & 15u;
     if (vm == 0u) return;
     float v[4];
     uint32_t rowbytes = 0;                             // byte k = mask bit of element k's row atom
     float4 xi0;
-    if (A == 1) xi0 = *reinterpret_cast<const float4*>(xi_row);
+    if (ACT == 1) xi0 = *reinterpret_cast<const float4*>(xi_row);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float4 xi = (A == 1) ? xi0 : *reinterpret_cast<const float4*>(xi_row + aoff[WO + k]);
+        const float4 xi = (ACT == 1) ? xi0 : *reinterpret_cast<const float4*>(xi_row + aoff[WO + k]);
         v[k] = dist_pp<EXACT>(xi, make_float4(col[WO + k][0], col[WO + k][1], col[WO + k][2], 0.f));
         rowbytes |= __float_as_uint(xi.w) << (8 * k);
     }
@@ -1177,19 +1182,23 @@ __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, c
     }
 }
 
-template <int A, bool EXACT>
+template <int ACT, bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restrict__ xyz,
                                                             const uint8_t* __restrict__ amask,
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
-                                                            int N, int row_begin, int row_end, int out_rows,
+                                                            int N, int A_rt, int row_begin, int row_end, int out_rows,
                                                             int out_row_origin, int IR, int n_tiles, int spt,
                                                             int n_ichunks, int lpg_log2, int xcd_remap) {
-    using T = RowPhase<A>;
-    constexpr int AA = T::AA, W = T::W;
+    using T = RowPhase<ACT>;
+    typedef typename T::bits_t bits_t;
+    constexpr int W = T::W;
+    const int A = ACT > 0 ? ACT : A_rt;                                 // a constant wherever ACT > 0
+    const int AA = A * A;
+    const int maxres = rowphase_maxres(A);
     extern __shared__ __attribute__((aligned(16))) char smem_rp[];
     float4* sxi = reinterpret_cast<float4*>(smem_rp);                   // [IR * A] row atoms: x, y, z, mask bit
-    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * A);          // [MAXRES] column mask bits
-    float* sxj = reinterpret_cast<float*>(smj + T::MAXRES);             // [MAXRES * A * 3] column coordinates, as in HBM
+    bits_t* smj = reinterpret_cast<bits_t*>(sxi + IR * A);              // [maxres] column mask bits
+    float* sxj = reinterpret_cast<float*>(smj + maxres);                // [maxres * A * 3] column coordinates, as in HBM
 
     const int tid = threadIdx.x;
     unsigned w = blockIdx.x;
@@ -1214,9 +1223,9 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     const int j_lo = t_lo / AA, j_hi = t_hi / AA, nres = j_hi - j_lo + 1;
 
     {   // stage: the tile's column residues are one contiguous float range of xyz; row atoms one float4 each
-        const float* gj = xyz + ((size_t)b * N + j_lo) * (A * 3);
+        const float* gj = xyz + ((size_t)b * N + j_lo) * (size_t)(A * 3);
         for (int f = tid; f < nres * (A * 3); f += 256) sxj[f] = gj[f];
-        const float* gi = xyz + ((size_t)b * N + i0) * (A * 3);
+        const float* gi = xyz + ((size_t)b * N + i0) * (size_t)(A * 3);
         float* li = reinterpret_cast<float*>(sxi);
         for (int f = tid; f < in * (A * 3); f += 256) {
             const int atom = f / 3, comp = f - atom * 3;
@@ -1225,12 +1234,16 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
         for (int f = tid; f < in * A; f += 256)      // fourth component: the row atom's mask bit
             reinterpret_cast<uint32_t*>(sxi)[f * 4 + 3] = amask ? (amask[((size_t)b * N + i0) * A + f] != 0 ? 1u : 0u) : 1u;
         for (int r = tid; r < nres; r += 256) {
-            uint32_t bits = (1u << A) - 1u;
+            bits_t bits = A >= 64 ? ~(bits_t)0 : (((bits_t)1 << (A & 63)) - 1);
             if (amask) {
                 const uint8_t* m = amask + ((size_t)b * N + j_lo + r) * A;
                 bits = 0;
+                if (ACT > 0) {
 #pragma unroll
-                for (int c = 0; c < A; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
+                    for (int c = 0; c < (ACT > 0 ? ACT : 1); ++c) bits |= (bits_t)(m[c] != 0 ? 1u : 0u) << c;
+                } else {
+                    for (int c = 0; c < A; ++c) bits |= (bits_t)(m[c] != 0 ? 1u : 0u) << c;
+                }
             }
             smj[r] = bits;
         }
@@ -1253,14 +1266,14 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                 const int t = 4 * s - T::W0 + wi;
                 const bool ok = s < s1 && t >= 0 && t < nel;
                 const unsigned e = ok ? (unsigned)t : (unsigned)t_lo;
-                const unsigned j = e / AA, r = e - j * AA;
-                const unsigned a = r / A, c = r - a * A;
+                const unsigned j = e / (unsigned)AA, r = e - j * (unsigned)AA;      // constant divisors when ACT > 0
+                const unsigned a = r / (unsigned)A, c = r - a * (unsigned)A;
                 const float* p = sxj + ((j - (unsigned)j_lo) * A + c) * 3;
                 col[u][wi][0] = p[0];
                 col[u][wi][1] = p[1];
                 col[u][wi][2] = p[2];
                 aoff[u][wi] = a * (unsigned)sizeof(float4);
-                cm[u] |= (ok ? ((smj[j - (unsigned)j_lo] >> c) & 1u) : 0u) << wi;
+                cm[u] |= (ok ? (uint32_t)((smj[j - (unsigned)j_lo] >> c) & 1u) : 0u) << wi;
                 valid[u] |= (ok ? 1u : 0u) << wi;
             }
         }
@@ -1282,13 +1295,13 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
             float* od = rd + so[u];
             uint8_t* om = rm + so[u];
             if constexpr (!T::PHASED) {
-                rowphase_slot<A, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm);
+                rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm);
             } else {
                 switch (ph) {   // uniform over the wave
-                    case 0: rowphase_slot<A, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    case 1: rowphase_slot<A, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    case 2: rowphase_slot<A, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    default: rowphase_slot<A, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 0: rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 1: rowphase_slot<ACT, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 2: rowphase_slot<ACT, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    default: rowphase_slot<ACT, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
                 }
             }
         }
@@ -1698,21 +1711,29 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
                  remap);
 }
 
-// Row-phase kernel: the small atom counts that have no multiple-of-4 row-tile kernel, any N, any row range.
-bool rowphase_has(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
+// Row-phase kernel: every atom count up to 64 other than 4, 8 (row-tile kernel) and 15; any N, any row range.  The small
+// counts are compile-time instantiations; the rest share the two run-time instantiations (even / odd A).  cfg.rowphase:
+// 0 = where it is the default (A <= 13, and the counts without a fixed-A flat kernel), 1 = every eligible count (A/B runs
+// against the fixed-A flat kernels), 2 = never (A/B runs against the flat / any-A kernels).
+bool rowphase_ct(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
+
+bool flatA_has(int A);
 
 bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
-    if (g.variant != 0 || g.flat != 1 || !rowphase_has(A)) return false;
+    if (g.variant != 0 || g.flat != 1 || g.rowphase == 2) return false;
+    if (A < 1 || A > 64 || A == 4 || A == 8) return false;
+    if (A == 15 && g.rowphase != 1) return false;                      // A = 15 has its own kernels
+    if (!rowphase_ct(A) && flatA_has(A) && g.rowphase != 1) return false;
     if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
-template <int A>
+template <int ACT>
 int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
-                    int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
-    using T = RowPhase<A>;
+                    int A, int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
+    using T = RowPhase<ACT>;
     const int rows = row_end - row_begin;
-    const int nel = N * T::AA;
+    const int nel = N * A * A;
     const int nslots = (nel + 3 + ((nel & 3) == 0 ? 0 : (nel & 3) == 2 ? 2 : 3)) / 4;   // over the phases that occur
     // short rows: 2 or 4 row groups of 128 / 64 lanes (every lane still takes ~32 rows), see the kernel
     const int lpg_log2 = nslots <= 128 ? 6 : (nslots <= 256 ? 7 : 8);
@@ -1725,14 +1746,18 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
-    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)T::MAXRES * 4 + (size_t)T::MAXRES * A * 3 * sizeof(float);
+    const int maxres = rowphase_maxres(A);
+    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)maxres * sizeof(typename T::bits_t) +
+                       (size_t)maxres * A * 3 * sizeof(float);
+    const int tp = ACT > 0 ? ACT : A;     // what the plan prints: the atom count
+    const char* name = ACT > 0 ? "k1_pairdist_rowphase" : (ACT == 0 ? "k1_pairdist_rowphase_rt_even" : "k1_pairdist_rowphase_rt_odd");
     if (g.exact_sqrt)
-        return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, true>, dim3((unsigned)n_wg),
-                     dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR,
-                     n_tiles, spt, n_ichunks, lpg_log2, remap);
-    return k1_go(go, "rowphase", "k1_pairdist_rowphase", A, k1_pairdist_rowphase<A, false>, dim3((unsigned)n_wg),
-                 dim3(256), lds, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles,
-                 spt, n_ichunks, lpg_log2, remap);
+        return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, true>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
+                     amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
+                     lpg_log2, remap);
+    return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, false>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
+                 amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
+                 lpg_log2, remap);
 }
 
 // Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37 -- for
@@ -1826,6 +1851,7 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
     if (g.anya_fl_log2 != 0 && (g.anya_fl_log2 < 4 || g.anya_fl_log2 > 10)) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
+    if (g.rowphase < 0 || g.rowphase > 2) return false;
 #ifdef PS_EXPERIMENTS
     if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
 #else
@@ -1872,13 +1898,16 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (rowphase_eligible(g, dist, dist_mask, N, A)) {
-#define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
+#define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);
         switch (A) {
             PS_K1_RP(1) PS_K1_RP(2) PS_K1_RP(3) PS_K1_RP(5) PS_K1_RP(6) PS_K1_RP(7) PS_K1_RP(9) PS_K1_RP(10) PS_K1_RP(11)
             PS_K1_RP(12) PS_K1_RP(13)
             default: break;
         }
 #undef PS_K1_RP
+        if (A & 1)
+            return launch_rowphase<-1>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);
+        return launch_rowphase<0>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (flatA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure

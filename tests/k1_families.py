@@ -32,13 +32,19 @@ FAMILY_SHAPES = [
     (2, 40, 7, None, False, {}, "rowphase"),
     (1, 30, 13, None, False, {}, "rowphase"),
     (2, 6, 3, None, False, {}, "rowphase"),
-    # any-A flat kernel: atom counts without a fixed-A kernel
-    (2, 40, 20, None, False, {}, "anyA"),
-    (2, 17, 33, (0, 9), True, {}, "anyA"),
+    # ... and, through its run-time atom-count instantiations (even / odd), every other count up to 64
+    (2, 40, 20, None, False, {}, "rowphase"),
+    (2, 17, 33, (0, 9), True, {}, "rowphase"),
+    (1, 9, 64, None, False, {}, "rowphase"),
+    (2, 10, 21, None, False, {}, "rowphase"),
+    (2, 33, 14, None, False, {"k1_rowphase": 1}, "rowphase"),
+    # any-A flat kernel (the round-1 kernel for counts without a fixed-A kernel; k1_rowphase = 2 or k1_flat = 3 reach it)
+    (2, 40, 20, None, False, {"k1_rowphase": 2}, "anyA"),
+    (2, 17, 33, (0, 9), True, {"k1_rowphase": 2}, "anyA"),
     (2, 40, 7, None, False, {"k1_flat": 3}, "anyA"),
-    # element-per-lane kernel: A > 64, N < 16 without a row-phase kernel, or the simple variant
+    # element-per-lane kernel: A > 64, or nothing else eligible (N < 16 without the row-phase kernel; the simple variant)
     (1, 8, 70, None, False, {}, "element"),
-    (2, 10, 20, None, False, {}, "element"),
+    (2, 10, 20, None, False, {"k1_rowphase": 2}, "element"),
     (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
 ]
 

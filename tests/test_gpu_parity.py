@@ -335,7 +335,7 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
     against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
     at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
-    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt")
+    keys = ("k1_variant", "k1_flat", "k1_flat_cpw", "k1_store_nt", "k1_exact_sqrt", "k1_rowphase")
     saved = {k: _lib.get_tuning(k) for k in keys}
     _lib.set_tuning("k1_exact_sqrt", exact)
     SENT = 12345.0
@@ -362,19 +362,25 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              (2, 2, 2), (2, 99, 2), (2, 100, 6), (2, 37, 7), (2, 3, 7), (1, 64, 9), (2, 50, 10), (2, 33, 11), (1, 40, 12),
              (2, 29, 13), (1, 90, 5), (1, 91, 5), (1, 93, 3), (1, 94, 3),
              # the fixed-A flat pattern kernels added in round 3
-             (2, 40, 24), (1, 33, 27), (1, 30, 32)]
+             (2, 40, 24), (1, 33, 27), (1, 30, 32),
+             # atom counts served by the run-time instantiations of the row-phase kernel (even / odd), short and long rows
+             (2, 40, 20), (1, 37, 33), (1, 9, 64), (2, 10, 21), (1, 70, 18), (1, 45, 40), (1, 31, 63), (2, 5, 17)]
 
     def paths(A):
-        """k1_flat settings that reach a fast kernel for this atom count (1: default dispatch = row-tile / row-phase
-        kernels; 3: any-A flat kernel; 4: fixed-A flat pattern kernel)."""
+        """(k1_flat, k1_rowphase) settings that reach a fast kernel for this atom count.  k1_flat 1: default dispatch
+        (row-tile / row-phase kernels, fixed-A flat kernels); 3: any-A flat kernel; 4: fixed-A flat pattern kernel.
+        k1_rowphase 1: the row-phase kernel also where a fixed-A flat kernel is the default; 2: never."""
         if A in (1, 2, 3):
-            return [1]
+            return [(1, 0)]
+        if A in (4, 8):
+            return [(1, 0), (3, 0)]
         if A in (14, 15, 16, 24, 25, 27, 32, 37):
-            return [3, 4]
-        return [1, 3] if A <= 13 else [3]
+            return [(3, 0), (4, 0), (1, 1)]
+        return [(1, 0), (3, 0)]
 
     try:
-        for (B, N, A), flat in [(c, f) for c in cases for f in paths(c[2])]:
+        for (B, N, A), (flat, rowphase) in [(c, f) for c in cases for f in paths(c[2])]:
+            _lib.set_tuning("k1_rowphase", rowphase)
             xyz, mask = synth(300 + N + A, B, N, A=A)
             xyz[0, N // 3] = float("nan")
             mask[0, N // 3] = False
@@ -395,8 +401,8 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
                 d = bd[pad:pad + numel].view(ref_d.shape)
                 m = bm[pad:pad + numel].view(torch.bool).view(ref_m.shape)
                 ops.pairwise_distance(xg, mg, out_dist=d, out_mask=m)
-                assert _same_floats(d, ref_d), (B, N, A, cpw, flat)
-                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat)
+                assert _same_floats(d, ref_d), (B, N, A, cpw, flat, rowphase)
+                assert torch.equal(m, ref_m) and torch.equal(m.cpu(), rm), (B, N, A, cpw, flat, rowphase)
                 assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all()
                 assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all()
                 d0, _ = ops.pairwise_distance(xg, None, want_mask=False)

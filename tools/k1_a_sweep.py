@@ -15,7 +15,8 @@ from protstruc_amd import _lib, ops
 out_json = None
 shapes = [(14, 256), (14, 250), (37, 128), (37, 100), (15, 256), (4, 512), (4, 500), (5, 512), (5, 500), (5, 501), (8, 256),
           (3, 512), (3, 500), (3, 501), (16, 256), (25, 128), (1, 512), (1, 500), (1, 501), (2, 512), (2, 501), (7, 512),
-          (7, 500), (10, 512), (10, 500), (6, 501), (13, 250)]
+          (7, 500), (10, 512), (10, 500), (6, 501), (13, 250), (20, 128), (20, 125), (33, 100), (24, 128), (27, 128), (32, 128),
+          (64, 64), (15, 512), (15, 500)]
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     if k == "json": out_json = v
@@ -28,7 +29,7 @@ for A, N in shapes:
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
     d = torch.empty(B, N, N, A, A, device="cuda"); m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-    variants = {"default": (1, True, True, 0), "anyA": (3, True, True, 0),
+    variants = {"default": (1, True, True, 0), "rowphase": (1, True, True, 1), "anyA": (3, True, True, 0),
                 "element": (0, True, True, 0), "default_dist_only": (1, True, False, 0),
                 "default_mask_only": (1, False, True, 0), "fill": None}
     best = {k: float("inf") for k in variants}
@@ -38,8 +39,9 @@ for A, N in shapes:
             if var is None:
                 run = lambda: (d.fill_(0.0), m.fill_(False))
             else:
-                flat, wd, wm, small_a = var
+                flat, wd, wm, rowphase = var
                 _lib.set_tuning("k1_flat", flat)
+                _lib.set_tuning("k1_rowphase", rowphase)
                 run = lambda: ops.pairwise_distance(xyz, mask, out_dist=d if wd else None, out_mask=m if wm else None,
                                                     want_dist=wd, want_mask=wm)
             for _ in range(2): run()
@@ -50,7 +52,8 @@ for A, N in shapes:
             e1.record(); torch.cuda.synchronize()
             best[name] = min(best[name], e0.elapsed_time(e1) / 5)
     _lib.set_tuning("k1_flat", 1)
-    nbytes = {"default": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
+    _lib.set_tuning("k1_rowphase", 0)
+    nbytes = {"default": 5, "rowphase": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
     row = {"A": A, "N": N, "B": B, "kernel": _lib.k1_plan(B, N, A)["kernel"], **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
                                      for k, v in best.items()}}
     rows.append(row)
