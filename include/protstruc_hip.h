@@ -58,10 +58,12 @@ const char* ps_error_string(int code);
 typedef struct ps_k1_config {
     int struct_size;      /* = sizeof(ps_k1_config); a launcher refuses any other value (caller built against another header) */
     int exact_sqrt;       /* 0: hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise); 1: correctly rounded */
-    int variant;          /* 0: fast kernels (pattern / flat pattern / fixed-A flat / any-A flat); 1: the simple kernels
-                             everywhere (slot-decode kernel for A = 15, element-per-lane kernel otherwise) */
-    int flat;             /* flat kernels: 0 never; 1 where they are the fast path (default); 2 force the A = 15 flat
-                             pattern kernel; 3 force the any-A flat kernel; 4 force the fixed-A flat pattern kernel */
+    int variant;          /* 0: fast kernels (pattern / flat pattern / row-tile / row-phase / fixed-A flat); 1: the simple
+                             kernels everywhere (slot-decode kernel for A = 15, element-per-lane kernel otherwise) */
+    int flat;             /* 0: none of the fast kernels for A != 15 and no flat kernel for A = 15; 1 (default): every kernel
+                             where it is the fast path; 2: force the A = 15 flat pattern kernel; 4: force the fixed-A flat
+                             pattern kernel (A = 14, 15, 16, 24, 32) and no row-tile / row-phase kernel.  (3 was the any-A
+                             flat kernel of rounds 1-2, removed: the row-phase kernel is faster at every atom count) */
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1) */
     int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 8) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
@@ -69,7 +71,6 @@ typedef struct ps_k1_config {
     int jt;               /* pattern kernel: column residues per tile, 64 / 128, 0 = auto */
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
-    int anya_fl_log2;     /* any-A flat kernel: log2(pairs per chunk), 0 = auto */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
     int rowphase;         /* row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
                              dispatch -- A <= 13 and every count without a fixed-A flat kernel; 1 also for A = 14, 15, 16, 24,
@@ -98,10 +99,10 @@ void ps_k1_config_default(ps_k1_config* cfg);
  * `atom_mask` may be NULL (all atoms present); `dist_mask` may be NULL (mask
  * plane not produced); `dist` may be NULL (only the mask plane produced).
  * Limits (hipErrorInvalidValue beyond them): B * out_rows * N < 2^32 pairs per launch for the flat kernels
- * (any N >= 16 that is not a multiple of 16, and every fixed-A atom count), 2^31 workgroups for the pattern kernel
- * (A = 15, N % 16 == 0); B <= 65535 only for the two simple kernels that put the structure on grid.z (N < 16,
- * unaligned planes, atom counts without a flat kernel).  K2 / K3 run on 1-D
- * grids: any batch size up to 2^31 workgroups per launch.
+ * (A = 15 at any N >= 16 that is not a multiple of 16; A = 14, 16, 24, 32), 2^31 workgroups for the pattern, row-tile
+ * and row-phase kernels (the latter also N * A * A <= 2^28); B <= 65535 only for the two simple kernels that put the
+ * structure on grid.z (A = 15 at N < 16 or on unaligned planes; A > 64; unaligned planes).  K2 / K3 run on 1-D grids:
+ * any batch size up to 2^31 workgroups per launch.
  * Arithmetic: sqrt((dx*dx + dy*dy) + dz*dz) in fp32 without contraction; the square
  * root is the hardware instruction (exact for 85 % of inputs, 1 ulp off otherwise)
  * unless ps_k1_config.exact_sqrt selects the correctly rounded routine.
@@ -133,7 +134,7 @@ int ps_pairwise_distance_cfg_f32(const float* xyz, const uint8_t* atom_mask,
 typedef struct ps_k1_plan {
     int struct_size;            /* in: sizeof(ps_k1_plan) */
     int n_launches;             /* 0 (empty input) or 1 (every kernel writes both planes in one launch) */
-    char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" | "anyA" |
+    char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" |
                                    "element" (other atom counts); "empty"; a second launch would be appended with " + " */
     char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<128>" */
     unsigned n_workgroups;      /* grid of the first launch */

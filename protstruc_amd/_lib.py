@@ -17,7 +17,7 @@ class K1Config(ctypes.Structure):
     """``ps_k1_config`` of include/protstruc_hip.h, field for field."""
     _fields_ = [(name, ctypes.c_int) for name in (
         "struct_size", "exact_sqrt", "variant", "flat", "rows_per_block", "lds_pad_kb", "flat_cpw",
-        "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "anya_fl_log2", "flat_fl_log2", "rowphase", "experiment")]
+        "flat_lds_pad_kb", "jt", "xcd_remap", "store_nt", "flat_fl_log2", "rowphase", "experiment")]
 
 
 class K1Plan(ctypes.Structure):
@@ -140,7 +140,7 @@ _K1_KEYS = {   # tuning key -> (struct field, lowest, highest)
     "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", 0, 120),
     "k1_flat_cpw": ("flat_cpw", 1, 64), "k1_flat_lds_pad_kb": ("flat_lds_pad_kb", 0, 100),
     "k1_jt": ("jt", 0, 128), "k1_xcd_remap": ("xcd_remap", 0, 1), "k1_store_nt": ("store_nt", 0, 1),
-    "k1_anya_fl_log2": ("anya_fl_log2", 0, 10), "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 2), "k1_experiment": ("experiment", 0, 31),
+    "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 2), "k1_experiment": ("experiment", 0, 31),
 }
 _k1_lock = threading.RLock()
 _k1_table = {}   # device index -> {field: value}
@@ -238,7 +238,7 @@ def set_tuning(key, value, device=None):
         raise HipLibraryError(f"unknown tuning key {key!r} (known: {', '.join(sorted(_K1_KEYS))})")
     field, lo, hi = _K1_KEYS[key]
     if not lo <= value <= hi or (key == "k1_jt" and value not in (0, 64, 128)) \
-            or (key in ("k1_anya_fl_log2", "k1_flat_fl_log2") and value in (1, 2, 3)):
+            or (key == "k1_flat_fl_log2" and value in (1, 2, 3)) or (key == "k1_flat" and value == 3):
         raise HipLibraryError(f"tuning value {key}={value} outside its range")
     if key == "k1_experiment" and value and not load().ps_has_experiments():
         raise HipLibraryError("timing experiments are not compiled into the product library "

@@ -26,10 +26,11 @@
 // over the flat pair axis, so rows need no alignment at all); the slot-decode kernel described above remains for
 // N < 16, unaligned planes and as the bit-identity cross-check in the tests.
 //
-// Other atom counts: A = 4, 8 the row-tile kernel and A = 1, 2, 3, 5-7, 9-13 the row-phase kernel (column atoms
-// stationary in registers, any N); A = 14, 16, 24, 25, 27, 32, 37 the fixed-A flat pattern kernel; any other
-// 4 <= A <= 64 the any-A flat kernel; what is left (A > 64, unaligned planes) the element-per-lane kernel at the
-// bottom.  ps_k1_plan_f32 reports which one a given launch takes (the dispatcher below, run in record-only mode).
+// Other atom counts: A = 4, 8 the row-tile kernel; A = 14, 16, 24, 32 the fixed-A flat pattern kernel; every other
+// A <= 64 the row-phase kernel (column atoms stationary in registers, any N; compile-time instantiations for the small
+// counts, two run-time ones -- even / odd A -- for the rest); what is left (A > 64, unaligned planes) the
+// element-per-lane kernel at the bottom.  ps_k1_plan_f32 reports which one a given launch takes (the dispatcher below,
+// run in record-only mode).
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
@@ -697,53 +698,37 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
     }
 }
 
-// ---- fixed-A flat pattern kernel (compile-time atom count, any N >= 16, 16-byte aligned planes) ----
-// The A = 15 flat pattern kernel generalised to a compile-time atom count A with A*A >= 129 (12 <= A <= 64): atom14
-// and atom37 are the layouts real pipelines use next to the reference's 15 slots (`from_xyz` accepts any A,
-// protstruc.py:94-128, tests/test_StructureBatch.py:11-21).  Four consecutive pairs are A*A float4 slots and sixteen
-// consecutive pairs are A*A 16-byte mask slots for EVERY A (a pair is A*A elements and the planes start 16-byte
-// aligned), so the fixed-lane pattern carries over: slot s of a group always decodes to the same (pair offset, a, c).
-// What changes with A:
-//   * A*A can exceed the 256 lanes: lane t owns slots t, t + 256, ... (SPL = ceil(A*A / 256) per group; atom37: 6).
-//     The sweep takes one slot set at a time (u outer, the chunk's groups inner), so only ONE slot's pattern -- four
-//     column-atom offsets, four row atoms -- is live in registers whatever SPL is (the first cut kept all six and
-//     spilled 247 VGPRs);
-//   * staging deals LPR = next power of two >= A lanes to a residue, and a residue's LDS image is RS float4 slots:
-//     16 for A <= 16 (atoms of one residue on distinct banks), A for larger A with the atom order permuted by the
-//     inverse of 4 mod A, so that the 16 lanes of a service group -- whose atoms are 4 apart -- read consecutive
-//     LDS slots instead of slots 64 bytes * k apart (bank conflicts);
-//   * mask rows are A bits wide: a 16-byte mask slot spans up to 2 + 14/A rows; words are 64-bit when A > 32.
-// Bit-identical to the element-per-lane kernel and to the any-A flat kernel (tests/test_gpu_k1_fuzz.py).
+// ---- fixed-A flat pattern kernel (compile-time EVEN atom count, any N >= 16, 16-byte aligned planes) ----
+// The A = 15 flat pattern kernel generalised to a compile-time atom count A with A*A >= 129: atom14 and the other even
+// counts (`from_xyz` accepts any A, protstruc.py:94-128, tests/test_StructureBatch.py:11-21).  Four consecutive pairs
+// are A*A float4 slots and sixteen consecutive pairs are A*A 16-byte mask slots for EVERY A (a pair is A*A elements and
+// the planes start 16-byte aligned), so the fixed-lane pattern carries over: slot s of a group always decodes to the same
+// (pair offset, a, c), and chunks of whole pairs are 128-byte-line aligned for any N.  What changes with A:
+//   * A*A can exceed the 256 lanes: lane t owns slots t, t + 256, ... (SPL = ceil(A*A / 256) per group).  The sweep
+//     takes one slot set at a time (u outer, the chunk's groups inner), so only ONE slot's pattern -- four column-atom
+//     offsets, four row atoms -- is live in registers whatever SPL is;
+//   * staging deals LPR = next power of two >= A lanes to a residue, and a residue's LDS image is RS float4 slots
+//     (16 for A <= 16: the atoms of one residue on distinct banks; A for larger A);
+//   * mask rows are A bits wide: a 16-byte mask slot spans up to 2 + 14/A rows; words are 64-bit from A = 32.
+// Odd counts take the row-phase kernel (faster there); bit-identical to it and to the element-per-lane kernel
+// (tests/test_gpu_k1_fuzz.py).
 template <int A>
 struct FlatA {
-    static_assert(A >= 12 && A <= 64, "fixed-A flat kernel: 12 <= A <= 64");
+    static_assert(A >= 12 && A <= 64 && (A % 2 == 0 || A == 15), "fixed-A flat kernel: even atom counts (and 15 as the cross-check)");
     static constexpr int AA = A * A;
     static constexpr int LPR = A <= 16 ? 16 : (A <= 32 ? 32 : 64);       // lanes per staged residue
     static constexpr int RPP = 256 / LPR;                                 // residues staged per pass
     static constexpr int RS = A <= 16 ? 16 : A;                           // float4 slots per staged residue
     static constexpr int SPL = (AA + 255) / 256;                          // slots per lane per group
-    // pairs per chunk: 128 / 64 / 32 / 16 by atom count.  For 25 <= A <= 40 both neighbours were A/B-tested in one
-    // process against 32 (tools/k1_ab_libs.py, profiles/r02_k1_ab_chunk_length.log): 64 pairs 5.5-5.8 TB/s and 16 pairs
-    // 5.1-5.4 against 5.9-6.3 (atom37 / A = 25)
+    // pairs per chunk: 128 / 64 / 32 / 16 by atom count (A/B-tested in round 2: profiles/r02_k1_ab_chunk_length.log)
     static constexpr int FL_LOG2 = A <= 16 ? 7 : (A <= 24 ? 6 : (A <= 40 ? 5 : 4));
     static constexpr int FLn = 1 << FL_LOG2;                              // pairs per chunk
     static constexpr int NR = (15 + FLn - 1) / 16 + 1;                    // rows a chunk can touch (N >= 16)
     static constexpr int FRn = ((NR + RPP - 1) / RPP) * RPP;              // row residues staged per chunk
     static constexpr int MROWS = 2 + 14 / A;                              // mask rows a 16-byte slot can span
-    static constexpr unsigned minv() {                                    // 4 * minv = 1 (mod A) for odd A > 16
-        if (A <= 16 || A % 2 == 0) return 1u;
-        for (unsigned m = 1; m < (unsigned)A; ++m)
-            if ((4u * m) % (unsigned)A == 1u) return m;
-        return 1u;
-    }
     // (A = 32 needs the wide word too: the all-atoms mask is (1 << A) - 1)
     typedef typename std::conditional<(A >= 32), unsigned long long, uint32_t>::type mask_t;
 };
-
-template <int A>
-__device__ __forceinline__ unsigned swz_atom(unsigned c) {
-    return FlatA<A>::minv() == 1u ? c : (c * FlatA<A>::minv()) % (unsigned)A;
-}
 
 template <int A, bool EXACT, bool HASMASK>
 __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restrict__ xyz,
@@ -769,7 +754,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
     }
     const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows;
     const int pl = tid / LPR, cl = tid % LPR;          // staging: LPR lanes per residue
-    const unsigned cs = (cl < A) ? swz_atom<A>((unsigned)cl) : (unsigned)cl;   // LDS slot of this lane's atom
+    const unsigned cs = (unsigned)cl;                  // LDS slot of this lane's atom
     const mask_t abits = (A >= 64) ? ~(mask_t)0 : (((mask_t)1 << (A & 63)) - 1);
 
     const unsigned n_chunks = n_ranges * cpr;
@@ -873,8 +858,8 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
                     jo[kk] = e / AA;
                     const unsigned r = e - jo[kk] * AA;
                     const unsigned a = r / A, c = r - a * A;
-                    offj[kk] = jo[kk] * RSn + swz_atom<A>(c);
-                    ai[kk] = swz_atom<A>(a);
+                    offj[kk] = jo[kk] * RSn + c;
+                    ai[kk] = a;
                 }
                 float* o = dist + (size_t)P0 * AA + 4u * sl;
                 int rl = 0;                // row of pair 4g
@@ -1308,220 +1293,6 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     }
 }
 
-// ---- flat kernel for any atom count 4 <= A <= 64 (N >= 16, 16-byte aligned planes) ----
-// Same flat pair axis and pair-position LDS image as the A = 15 flat kernel, but with A a run-time value there is no
-// fixed per-lane pattern: the chunk's float4 slots are dealt to lanes round-robin and each slot decodes its first
-// element into (pair position, a, c) with reciprocal multiplies and walks the other three with carries.  The mask
-// plane is built once per chunk as a BIT stream in LDS -- row (p, a) contributes m_i[a] ? bits(m_j) : 0 at bit
-// p*A*A + a*A via ds_or -- and a 16-byte mask slot is then just an aligned 16-bit half-word of that stream.
-// Replaces the element-per-lane kernel below (1.8-2.5 TB/s) wherever it applies.
-constexpr unsigned NO_RES = 0xFFFFFFFFu;
-
-template <bool EXACT, bool HASMASK>
-__global__ __launch_bounds__(256, 4) void k1_pairdist_anyA_flat(
-    const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ dist,
-    uint8_t* __restrict__ dmask, int B, int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
-    unsigned n_ranges, unsigned range_stride, unsigned cpr, int fl_log2, int FRr, int cpw, int xcd_remap,
-    double rcpN_d, double rcpR_d) {
-    extern __shared__ __attribute__((aligned(16))) char smem_any[];
-    const int FLr = 1 << fl_log2;
-    const unsigned AA = (unsigned)A * (unsigned)A;
-    // LDS carve: sx[(FL + FR) * A] float4 (column residues by pair position, then the touched row residues)
-    //            | smj[FL] u64 | smi[FR] u64 | sbits[FL*AA/32 + 2] u32 | ssrc[FL + FR] u32 | srl[FL] u32
-    float4* sx = reinterpret_cast<float4*>(smem_any);
-    unsigned long long* smj = reinterpret_cast<unsigned long long*>(sx + (size_t)(FLr + FRr) * A);
-    unsigned long long* smi = smj + FLr;
-    uint32_t* sbits = reinterpret_cast<uint32_t*>(smi + FRr);
-    const unsigned nwords = ((unsigned)FLr * AA >> 5) + 2u;
-    uint32_t* ssrc = sbits + nwords;
-    uint32_t* srl = ssrc + (FLr + FRr);
-
-    const int tid = threadIdx.x;
-    unsigned w = blockIdx.x;
-    if (xcd_remap) {
-        const unsigned n = gridDim.x, x = w & 7u;
-        w = x * (n >> 3) + min(x, n & 7u) + (w >> 3);
-    }
-    const float rcpN = 1.0f / (float)N, rcpR = 1.0f / (float)out_rows, rcpA = 1.0f / (float)A,
-                rcpAA = 1.0f / (float)AA;
-    const unsigned long long allbits = (A >= 64) ? ~0ull : ((1ull << A) - 1ull);
-    const unsigned n_chunks = n_ranges * cpr;
-
-    for (int cc = 0; cc < cpw; ++cc) {
-        const unsigned chunk = w * (unsigned)cpw + (unsigned)cc;
-        if (chunk >= n_chunks) break;  // uniform
-        if (cc) __syncthreads();
-        unsigned rg = 0, k = chunk;
-        if (n_ranges > 1) {
-            rg = chunk / cpr;
-            k = chunk - rg * cpr;
-        }
-        const unsigned rbeg = pbeg + rg * range_stride, rend = pend + rg * range_stride;
-        const unsigned P0 = ((rbeg >> fl_log2) + k) << fl_log2;
-        if (P0 >= rend) continue;  // uniform
-        const int lo = rbeg > P0 ? (int)(rbeg - P0) : 0;
-        const int hi = rend - P0 < (unsigned)FLr ? (int)(rend - P0) : FLr;
-        unsigned R0 = (unsigned)((double)P0 * rcpN_d);
-        if (R0 * (unsigned long long)N > P0) --R0;
-        else if ((R0 + 1ull) * N <= P0) ++R0;
-        const int j_start = (int)(P0 - R0 * (unsigned)N);
-        unsigned b0 = (unsigned)((double)R0 * rcpR_d);
-        if (b0 * (unsigned long long)out_rows > R0) --b0;
-        else if ((b0 + 1ull) * out_rows <= R0) ++b0;
-        const unsigned il0 = R0 - b0 * (unsigned)out_rows;
-        const int nr = (j_start + FLr - 1) / N + 1;  // rows the chunk touches (<= FRr)
-
-        // ---- pass 1: per pair position / per row: source residue, row index, atom-mask bits ----
-        for (int t = tid; t < FLr + FRr; t += 256) {
-            unsigned res = NO_RES;
-            if (t < FLr) {
-                const unsigned x = (unsigned)(j_start + t);
-                const unsigned rl = udiv_rcp(x, (unsigned)N, rcpN);
-                const unsigned j = x - rl * (unsigned)N;
-                const unsigned bb = b0 + udiv_rcp(il0 + rl, (unsigned)out_rows, rcpR);
-                srl[t] = rl;
-                if (t >= lo && t < hi) res = bb * (unsigned)N + j;
-            } else {
-                const unsigned rr = (unsigned)(t - FLr);
-                const unsigned ilr = il0 + rr;
-                const unsigned db = udiv_rcp(ilr, (unsigned)out_rows, rcpR);
-                const unsigned bb = b0 + db;
-                if ((int)rr < nr && bb < (unsigned)B)
-                    res = bb * (unsigned)N + (ilr - db * (unsigned)out_rows + (unsigned)out_row_origin);
-            }
-            ssrc[t] = res;
-            if (dmask) {
-                unsigned long long bits = 0;
-                if (res != NO_RES) {
-                    if (HASMASK) {
-                        const uint8_t* m = amask + (size_t)res * A;
-                        for (int c = 0; c < A; ++c) bits |= (unsigned long long)(m[c] != 0) << c;
-                    } else {
-                        bits = allbits;
-                    }
-                }
-                (t < FLr ? smj[t] : smi[t - FLr]) = bits;
-            }
-        }
-        if (dmask)
-            for (unsigned q = tid; q < nwords; q += 256) sbits[q] = 0u;
-        __syncthreads();
-
-        // ---- pass 2: coordinates (four atoms per lane in flight), then the mask bit stream ----
-        {
-            const unsigned natoms = (unsigned)(FLr + FRr) * (unsigned)A;
-            for (unsigned base = tid; base < natoms; base += 4u * 256u) {
-                float vx[4], vy[4], vz[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned idx = base + 256u * u;
-                    vx[u] = vy[u] = vz[u] = 0.f;
-                    if (idx < natoms) {
-                        const unsigned q = udiv_rcp(idx, (unsigned)A, rcpA);
-                        const unsigned res = ssrc[q];
-                        if (res != NO_RES) {
-                            const size_t src = ((size_t)res * A + (idx - q * (unsigned)A)) * 3;
-                            vx[u] = xyz[src + 0];
-                            vy[u] = xyz[src + 1];
-                            vz[u] = xyz[src + 2];
-                        }
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const unsigned idx = base + 256u * u;
-                    if (idx < natoms) sx[idx] = make_float4(vx[u], vy[u], vz[u], 0.f);
-                }
-            }
-        }
-        if (dmask) {
-            const unsigned nrows = (unsigned)FLr * (unsigned)A;
-            for (unsigned idx = tid; idx < nrows; idx += 256) {
-                const unsigned p = udiv_rcp(idx, (unsigned)A, rcpA);
-                const unsigned a = idx - p * (unsigned)A;
-                const unsigned long long mi = smi[srl[p]];
-                if ((mi >> a) & 1ull) {
-                    const unsigned long long bits = smj[p];
-                    const unsigned o = p * AA + a * (unsigned)A;
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const uint32_t part = (uint32_t)(bits >> (32 * h));
-                        if (part) {
-                            const unsigned off = o + 32u * h, wi = off >> 5, sh = off & 31u;
-                            atomicOr(&sbits[wi], part << sh);
-                            if (sh) atomicOr(&sbits[wi + 1], part >> (32u - sh));
-                        }
-                    }
-                }
-            }
-        }
-        __syncthreads();
-
-        const float4* sxj = sx;
-        const float4* sxi = sx + (size_t)FLr * A;
-        if (dist) {
-            float* o = dist + (size_t)P0 * AA;
-            const unsigned nslots = ((unsigned)FLr * AA) >> 2;
-            for (unsigned sl = tid; sl < nslots; sl += 256) {
-                const unsigned e0 = 4u * sl;
-                unsigned p = udiv_rcp(e0, AA, rcpAA);
-                if ((int)p >= hi) break;  // later slots of this lane lie further on still
-                const unsigned r = e0 - p * AA;
-                unsigned a = udiv_rcp(r, (unsigned)A, rcpA);
-                unsigned c = r - a * (unsigned)A;
-                // A >= 4: the four elements of a slot see at most one wrap of c and touch at most two pairs, so
-                // every element's (pair, a, c) follows from the first one's with selects -- no branches, no chain
-                const unsigned p1 = min(p + 1u, (unsigned)FLr - 1u);
-                const unsigned ibase0 = srl[p] * (unsigned)A, ibase1 = srl[p1] * (unsigned)A;
-                const unsigned jbase0 = p * (unsigned)A;
-                float v[4];
-                int pk[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    unsigned ck = c + (unsigned)kk;
-                    const bool wc = ck >= (unsigned)A;
-                    ck = wc ? ck - (unsigned)A : ck;
-                    unsigned ak = a + (wc ? 1u : 0u);
-                    const bool wa = ak >= (unsigned)A;
-                    ak = wa ? 0u : ak;
-                    pk[kk] = (int)p + (wa ? 1 : 0);
-                    const unsigned ii = (wa ? ibase1 : ibase0) + ak;
-                    const unsigned jj = jbase0 + (wa ? (unsigned)A : 0u) + ck;
-                    v[kk] = dist_pp<EXACT>(sxi[ii], sxj[jj]);
-                }
-                if (pk[0] >= lo && pk[3] < hi) {
-                    store16<false>(o + e0, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
-                                                   __float_as_uint(v[3])));
-                } else {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        if (pk[kk] >= lo && pk[kk] < hi) o[e0 + kk] = v[kk];
-                }
-            }
-        }
-        if (dmask) {
-            uint8_t* o = dmask + (size_t)P0 * AA;
-            const unsigned nms = ((unsigned)FLr * AA) >> 4;
-            for (unsigned ms = tid; ms < nms; ms += 256) {
-                const unsigned e0 = 16u * ms;
-                const int p_first = (int)udiv_rcp(e0, AA, rcpAA);
-                if (p_first >= hi) break;
-                const int p_last = (int)udiv_rcp(e0 + 15u, AA, rcpAA);
-                const uint32_t win = (sbits[ms >> 1] >> (16u * (ms & 1u))) & 0xFFFFu;
-                if (p_first >= lo && p_last < hi) {
-                    store16<false>(o + e0, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
-                                                   spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
-                } else if (p_last >= lo) {
-                    for (unsigned t = 0; t < 16u; ++t) {
-                        const int pp = (int)udiv_rcp(e0 + t, AA, rcpAA);
-                        if (pp >= lo && pp < hi) o[e0 + t] = (uint8_t)((win >> t) & 1u);
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
@@ -1686,7 +1457,7 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
 
 // Row-tile kernel (A = 4, 8): any N, any row range; planes must be 16-byte aligned.
 bool rowtile_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int A) {
-    if (g.variant != 0 || g.flat != 1) return false;   // flat = 3 / 4 force the flat kernels (cross-checks), 0 the simple one
+    if (g.variant != 0 || g.flat != 1) return false;   // flat = 4 forces the flat kernels (cross-checks), 0 the simple one
     if (A != 4 && A != 8) return false;
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
@@ -1723,7 +1494,7 @@ bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, 
     if (g.variant != 0 || g.flat != 1 || g.rowphase == 2) return false;
     if (A < 1 || A > 64 || A == 4 || A == 8) return false;
     if (A == 15 && g.rowphase != 1) return false;                      // A = 15 has its own kernels
-    if (!rowphase_ct(A) && flatA_has(A) && g.rowphase != 1) return false;
+    if (flatA_has(A) && g.rowphase != 1) return false;                 // even counts with a fixed-A flat kernel
     if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
@@ -1738,11 +1509,17 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     // short rows: 2 or 4 row groups of 128 / 64 lanes (every lane still takes ~32 rows), see the kernel
     const int lpg_log2 = nslots <= 128 ? 6 : (nslots <= 256 ? 7 : 8);
     const int G = 256 >> lpg_log2, tile_slots = T::SPL << lpg_log2;
-    const int n_ichunks = (rows + 32 * G - 1) / (32 * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 G rows, balanced
+#ifndef PS_RP_ROWS
+#define PS_RP_ROWS 32      // rows per lane and workgroup (A/B builds only: tools/k1_ab_libs.py)
+#endif
+    const int n_ichunks = (rows + PS_RP_ROWS * G - 1) / (PS_RP_ROWS * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 G rows, balanced
     const int n_tiles = (nslots + tile_slots - 1) / tile_slots;
     int spt = (nslots + n_tiles - 1) / n_tiles;          // slots per tile-row, balanced over the tiles, whole waves
     spt = ((spt + 63) / 64) * 64;
     if (spt > tile_slots) spt = tile_slots;
+#ifdef PS_RP_UNBALANCED   // A/B builds only: full tiles and a short last one instead of balanced tiles
+    spt = tile_slots;
+#endif
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
@@ -1760,15 +1537,15 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
                  lpg_log2, remap);
 }
 
-// Fixed-A flat pattern kernels: instantiated for the atom counts real pipelines use next to 15 -- atom14, atom37 -- for
-// 25 (the atom count of the reference's own from_xyz test, tests/test_StructureBatch.py:11-21), 16, 24, 27 and 32.
-// A = 15 is instantiated as well so that the template can be cross-checked against the hand-specialised A = 15
-// kernels (cfg.flat == 4).  Atom counts up to 13 have the row-tile / row-phase kernels; every other count takes the
-// any-A flat kernel.
-bool flatA_has(int A) { return A == 14 || A == 15 || A == 16 || A == 24 || A == 25 || A == 27 || A == 32 || A == 37; }
+// Fixed-A flat pattern kernels: the EVEN atom counts 14 (atom14), 16, 24, 32, where their line-aligned chunks make them
+// as fast as the row-phase kernel on aligned lengths and faster on the others (profiles/
+// r03_k1_a_sweep_rowphase_runtime_vs_flatA.log: A = 14, N = 250 6.45 against 5.49 TB/s).  For odd counts the row-phase
+// kernel wins (25: 6.77 against 5.97; 27: 6.30 / 5.72; 37: 6.22 / 5.66), so their instantiations were removed.  A = 15
+// is instantiated so that the template can be cross-checked against the hand-specialised A = 15 kernels (cfg.flat == 4).
+bool flatA_has(int A) { return A == 14 || A == 15 || A == 16 || A == 24 || A == 32; }
 
 bool flatA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
-    if (g.variant != 0 || g.flat == 0 || g.flat == 3 || !flatA_has(A)) return false;
+    if (g.variant != 0 || g.flat == 0 || !flatA_has(A)) return false;
     if (A == 15 && g.flat != 4) return false;   // A = 15 has its own kernels
     if (N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
     if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;      // pair indices stay 32-bit
@@ -1799,57 +1576,13 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
 #undef PS_K1_FLATA
 }
 
-// Any-A flat kernel: chunk length (a power of two, >= 16 pairs) so that the LDS image stays near 40 KB.
-bool anyA_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int out_rows) {
-    if (g.variant != 0 || g.flat == 0) return false;
-    // A < 4: a chunk's output is smaller than its LDS image and the element kernel is no slower
-    if (A < 4 || A > 64 || N < 16 || N >= (1 << 22) || out_rows < 1 || out_rows >= (1 << 22)) return false;
-    if ((unsigned long long)B * out_rows * N > 0xFFFFFF00ull) return false;
-    if ((unsigned long long)B * N >= 0x7FFFFFFFull) return false;  // residue indices stay 32-bit
-    if ((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15)) return false;
-    return true;
-}
-
-int launch_anyA_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B,
-                     int N, int A, int out_rows, int out_row_origin, unsigned pbeg, unsigned pend,
-                     unsigned n_ranges, unsigned range_stride, const K1Go& go) {
-    if (pbeg >= pend || n_ranges == 0) return 0;
-    // largest power of two of pairs (16..256) whose LDS image (A float4 + A*A/8 bytes of mask bits per pair) stays
-    // under 25 KB: measured best or within 2 % of best for A = 4, 5, 8, 14, 16, 25, 37 (profiles/r01_k1_any_a.log)
-    int fl_log2 = 4;
-    while (fl_log2 < 8 && (size_t)(2 << fl_log2) * ((size_t)A * 16 + (size_t)A * A / 8) <= 25 * 1024) ++fl_log2;
-    if (g.anya_fl_log2) fl_log2 = g.anya_fl_log2;
-    const int FLr = 1 << fl_log2;
-    const int FRr = (FLr - 1) / N + 2;
-    const unsigned AA = (unsigned)A * A;
-    const size_t lds = (size_t)(FLr + FRr) * A * sizeof(float4) + (size_t)(FLr + FRr) * 8 +
-                       ((size_t)(FLr * AA >> 5) + 2) * 4 + (size_t)(FLr + FRr) * 4 + (size_t)FLr * 4;
-    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    const unsigned cpr = n_ranges == 1 ? ((pend + (FLr - 1)) >> fl_log2) - (pbeg >> fl_log2)
-                                       : ((pend - pbeg) >> fl_log2) + 2;
-    const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;
-    if (n_chunks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    const unsigned cpw = (n_chunks >= 16384u) ? (unsigned)g.flat_cpw : 1u;
-    const unsigned n_wg = (unsigned)((n_chunks + cpw - 1) / cpw);
-    const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
-    const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
-#define PS_K1_ANYA(EX_, HM_)                                                                                      \
-    k1_go(go, "anyA", "k1_pairdist_anyA_flat", -1, k1_pairdist_anyA_flat<EX_, HM_>, dim3(n_wg), dim3(256), lds,   \
-          xyz, amask, dist, dmask, B, N, A, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr,   \
-          fl_log2, FRr, (int)cpw, remap, rn, rr)
-    if (g.exact_sqrt) return amask ? PS_K1_ANYA(true, true) : PS_K1_ANYA(true, false);
-    return amask ? PS_K1_ANYA(false, true) : PS_K1_ANYA(false, false);
-#undef PS_K1_ANYA
-}
-
 // Range checks of a caller-supplied configuration; the defaults pass by construction.
 bool cfg_valid(const K1Cfg& g) {
     if (g.struct_size != (int)sizeof(K1Cfg)) return false;
-    if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4) return false;
+    if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4 || g.flat == 3) return false;
     if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < 0 || g.lds_pad_kb > 120) return false;
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
     if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
-    if (g.anya_fl_log2 != 0 && (g.anya_fl_log2 < 4 || g.anya_fl_log2 > 10)) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
     if (g.rowphase < 0 || g.rowphase > 2) return false;
 #ifdef PS_EXPERIMENTS
@@ -1920,20 +1653,9 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
             case 15: return launch_flatA<15>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 16: return launch_flatA<16>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 24: return launch_flatA<24>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 25: return launch_flatA<25>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 27: return launch_flatA<27>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             case 32: return launch_flatA<32>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
-            case 37: return launch_flatA<37>(g, xyz, atom_mask, dist, dist_mask, B, N, out_rows, out_row_origin, r0, r1, nrg, stride, go);
             default: break;
         }
-    }
-    if ((A != A15 || g.flat == 3) && anyA_eligible(g, dist, dist_mask, B, N, A, out_rows)) {
-        if (rows == out_rows)
-            return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, 0u,
-                                    (unsigned)((unsigned long long)B * out_rows * N), 1u, 0u, go);
-        const unsigned r0 = (unsigned)(row_begin - out_row_origin) * (unsigned)N;
-        return launch_anyA_flat(g, xyz, atom_mask, dist, dist_mask, B, N, A, out_rows, out_row_origin, r0,
-                                r0 + (unsigned)rows * (unsigned)N, (unsigned)B, (unsigned)out_rows * (unsigned)N, go);
     }
     if (A == A15 && flat_eligible(g, dist, dist_mask, B, N, out_rows)) {
         // one contiguous pair range when every output row is computed, else the same rows of every structure

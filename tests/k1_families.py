@@ -16,11 +16,11 @@ FAMILY_SHAPES = [
     (2, 64, 15, None, False, {"k1_flat": 2, "k1_flat_fl_log2": 5}, "flat"),
     (2, 12, 15, None, False, {}, "slot_decode"),
     (2, 48, 15, None, False, {"k1_variant": 1}, "slot_decode"),
-    # fixed-A flat pattern kernels (atom14, atom37, 16, 24, 25, 27, 32; A = 15 with k1_flat = 4 as the cross-check)
+    # fixed-A flat pattern kernels (the even counts 14, 16, 24, 32; A = 15 with k1_flat = 4 as the cross-check)
     (2, 40, 14, None, False, {}, "flatA"),
-    (1, 20, 37, (3, 17), False, {}, "flatA"),
-    (2, 33, 25, None, False, {}, "flatA"),
-    (2, 19, 27, (2, 19), True, {}, "flatA"),
+    (1, 20, 32, (3, 17), False, {}, "flatA"),
+    (2, 33, 24, None, False, {}, "flatA"),
+    (2, 19, 16, (2, 19), True, {}, "flatA"),
     (2, 35, 15, None, False, {"k1_flat": 4}, "flatA"),
     # row-tile kernels of A = 4, 8
     (2, 40, 4, None, False, {}, "rowtile"),
@@ -38,14 +38,12 @@ FAMILY_SHAPES = [
     (1, 9, 64, None, False, {}, "rowphase"),
     (2, 10, 21, None, False, {}, "rowphase"),
     (2, 33, 14, None, False, {"k1_rowphase": 1}, "rowphase"),
-    # any-A flat kernel (the round-1 kernel for counts without a fixed-A kernel; k1_rowphase = 2 or k1_flat = 3 reach it)
-    (2, 40, 20, None, False, {"k1_rowphase": 2}, "anyA"),
-    (2, 17, 33, (0, 9), True, {"k1_rowphase": 2}, "anyA"),
-    (2, 40, 7, None, False, {"k1_flat": 3}, "anyA"),
+    (1, 20, 37, (3, 17), False, {}, "rowphase"),
+    (2, 33, 25, None, False, {}, "rowphase"),
     # element-per-lane kernel: A > 64, or nothing else eligible (N < 16 without the row-phase kernel; the simple variant)
     (1, 8, 70, None, False, {}, "element"),
     (2, 10, 20, None, False, {"k1_rowphase": 2}, "element"),
     (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
 ]
 
-ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "anyA", "element"}
+ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "element"}

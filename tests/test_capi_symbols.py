@@ -93,7 +93,8 @@ def test_k1_config_is_validated_before_any_launch(lib_path):
     assert call(None) == 0 and call(_lib.k1_config(0)) == 0
     for field, value in [("struct_size", 8), ("struct_size", 0), ("experiment", 2), ("experiment", 1), ("variant", 2),
                          ("flat", 5), ("rows_per_block", 0), ("rows_per_block", 33), ("flat_cpw", 0), ("jt", 96),
-                         ("lds_pad_kb", 121), ("anya_fl_log2", 3), ("flat_lds_pad_kb", -1)]:
+                         ("lds_pad_kb", 121), ("flat_fl_log2", 3), ("flat_fl_log2", 8), ("flat", 3), ("rowphase", 3),
+                         ("flat_lds_pad_kb", -1)]:
         assert call(_lib.k1_config(0, **{field: value})) == 1, (field, value)
 
 

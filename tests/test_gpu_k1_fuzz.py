@@ -1,4 +1,4 @@
-"""Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, fixed-A flat, any-A flat, row-tile, row-phase) against its two simple kernels
+"""Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, fixed-A flat, row-tile, row-phase) against its two simple kernels
 (slot-decode for A = 15, element-per-lane otherwise): random shapes, row ranges, compact / in-place outputs, chunk
 counts per workgroup and both square-root modes; outputs sit inside sentinel-filled buffers.  -m gpu."""
 import numpy as np
@@ -51,7 +51,7 @@ def test_k1_fast_kernels_differential_fuzz():
             ref_d, ref_m = ops.pairwise_distance(xg, mg)
             # path under test
             _lib.set_tuning("k1_variant", 0)
-            _lib.set_tuning("k1_flat", int(rng.choice([1, 1, 2, 3, 4])) if A not in (1, 2) else 1)
+            _lib.set_tuning("k1_flat", int(rng.choice([1, 1, 2, 4])) if A not in (1, 2) else 1)
             _lib.set_tuning("k1_rowphase", int(rng.choice([0, 0, 1, 2])) if A not in (1, 2) else 0)
             _lib.set_tuning("k1_flat_cpw", int(rng.choice([1, 2, 3, 7])))
             _lib.set_tuning("k1_rows_per_block", int(rng.choice([1, 2, 4, 5])))

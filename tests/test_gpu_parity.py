@@ -330,8 +330,8 @@ def _same_floats(a, b):
 
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
-    """The vectorised any-A flat kernel (k1_flat=3), the fixed-A flat pattern kernels (k1_flat=4), the row-tile kernels
-    of A = 4 / 8 and the row-phase kernel of the other small atom counts (k1_flat=1, the default dispatch)
+    """The fixed-A flat pattern kernels (k1_flat=4), the row-tile kernels of A = 4 / 8 and the row-phase kernel of every
+    other atom count up to 64 (k1_flat=1, the default dispatch; k1_rowphase=1 where another kernel is the default)
     against the element-per-lane kernel (k1_flat=0) for atom counts other than 15 -- and against the pattern kernels
     at A = 15 -- over full, compact and in-place row ranges, with sentinel guards around every output."""
     from protstruc_amd import _lib, ops
@@ -368,15 +368,13 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
 
     def paths(A):
         """(k1_flat, k1_rowphase) settings that reach a fast kernel for this atom count.  k1_flat 1: default dispatch
-        (row-tile / row-phase kernels, fixed-A flat kernels); 3: any-A flat kernel; 4: fixed-A flat pattern kernel.
-        k1_rowphase 1: the row-phase kernel also where a fixed-A flat kernel is the default; 2: never."""
-        if A in (1, 2, 3):
-            return [(1, 0)]
+        (row-tile / row-phase kernels, fixed-A flat kernels for 14, 16, 24, 32); 4: fixed-A flat pattern kernel.
+        k1_rowphase 1: the row-phase kernel also where a fixed-A flat kernel or the A = 15 kernels are the default."""
         if A in (4, 8):
-            return [(1, 0), (3, 0)]
-        if A in (14, 15, 16, 24, 25, 27, 32, 37):
-            return [(3, 0), (4, 0), (1, 1)]
-        return [(1, 0), (3, 0)]
+            return [(1, 0)]
+        if A in (14, 15, 16, 24, 32):
+            return [(4, 0), (1, 1)]
+        return [(1, 0)]
 
     try:
         for (B, N, A), (flat, rowphase) in [(c, f) for c in cases for f in paths(c[2])]:
@@ -430,7 +428,7 @@ def test_k1_square_root_modes(SB):
     """K1's two arithmetic modes.  Exact mode is the correctly rounded sqrt of the fp32 sum ((dx^2 + dy^2) + dz^2):
     bit-identical to numpy evaluating that formula in float32.  The default mode uses the hardware square root: never
     more than 1 ulp away from exact mode, identical on most entries.  Every kernel behind the entry point is covered
-    (pattern, flat pattern, slot-decode, any-A flat, element-per-lane)."""
+    (pattern, flat pattern, slot-decode, row-tile, row-phase incl. its run-time atom counts, fixed-A flat, element-per-lane)."""
     from protstruc_amd import _lib, ops
     keys = ("k1_variant", "k1_flat", "k1_exact_sqrt")
     saved = {k: _lib.get_tuning(k) for k in keys}
@@ -443,7 +441,8 @@ def test_k1_square_root_modes(SB):
 
     try:
         for (B, N, A, variant, flat) in [(2, 64, 15, 0, 1), (2, 37, 15, 0, 1), (2, 37, 15, 1, 1), (2, 40, 5, 0, 1),
-                                         (2, 40, 5, 0, 0), (1, 24, 37, 0, 1)]:
+                                         (2, 40, 5, 0, 0), (1, 24, 37, 0, 1), (2, 33, 4, 0, 1), (2, 30, 14, 0, 1),
+                                         (1, 20, 40, 0, 1)]:
             xyz, mask = synth(900 + N + A, B, N, A=A, scale=float(N % 7 + 1))
             xg, mg = xyz.cuda(), mask.cuda()
             _lib.set_tuning("k1_variant", variant)
@@ -661,11 +660,13 @@ def test_k1_explicit_config_through_the_c_abi(SB):
     default = _lib.K1Config()
     lib.ps_k1_config_default(ctypes.byref(default))
     for over in [{}, {"rows_per_block": 4}, {"jt": 64, "rows_per_block": 3}, {"variant": 1}, {"flat": 2, "flat_cpw": 3},
-                 {"flat": 3}, {"flat": 0}, {"xcd_remap": 0, "store_nt": 1}, {"lds_pad_kb": 8}]:
+                 {"flat": 4}, {"flat": 0}, {"rowphase": 1}, {"rowphase": 2}, {"flat": 2, "flat_fl_log2": 5},
+                 {"xcd_remap": 0, "store_nt": 1}, {"lds_pad_kb": 8}]:
         cfg = _lib.K1Config(**{**{f: getattr(default, f) for f, _ in _lib.K1Config._fields_}, **over})
         rc, d, m = run(cfg)
         assert rc == 0 and torch.equal(d, ref_d) and torch.equal(m, ref_m), over
-    for over in [{"struct_size": 4}, {"experiment": 2}, {"rows_per_block": 0}, {"flat": 9}]:
+    for over in [{"struct_size": 4}, {"experiment": 2}, {"rows_per_block": 0}, {"flat": 9}, {"flat": 3}, {"rowphase": 3},
+                 {"flat_fl_log2": 2}]:
         cfg = _lib.K1Config(**{**{f: getattr(default, f) for f, _ in _lib.K1Config._fields_}, **over})
         rc, d, m = run(cfg)
         assert rc == 1 and (d == -3.0).all() and (m == 9).all(), over

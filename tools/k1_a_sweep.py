@@ -1,6 +1,6 @@
 """K1 store rate for atom counts other than 15, every kernel that can serve the shape timed in ONE process in
-interleaved rounds (never compare across runs / boxes): flat=1 (the default dispatch: fixed-A flat pattern kernel
-for atom14 / atom37, any-A flat kernel otherwise), flat=3 (any-A flat kernel), flat=0 (element-per-lane kernel);
+interleaved rounds (never compare across runs / boxes): the default dispatch, the row-phase kernel where another kernel
+is the default (rowphase=1), flat=0 (element-per-lane kernel);
 plus the default dispatch with only the distance plane / only the mask plane.
 Round 3: "fill" = torch.fill_ on the same two buffers (which class of allocation the shape drew).  (The "r2path" column
 of profiles/r03_k1_a_sweep_rowphase*.log was the round-2 dispatch -- odd row-tile kernels + k1_mask_rows, small fixed-A
@@ -29,7 +29,7 @@ for A, N in shapes:
     xyz = torch.randn(B, N, A, 3, generator=g).cuda()
     mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
     d = torch.empty(B, N, N, A, A, device="cuda"); m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-    variants = {"default": (1, True, True, 0), "rowphase": (1, True, True, 1), "anyA": (3, True, True, 0),
+    variants = {"default": (1, True, True, 0), "rowphase": (1, True, True, 1),
                 "element": (0, True, True, 0), "default_dist_only": (1, True, False, 0),
                 "default_mask_only": (1, False, True, 0), "fill": None}
     best = {k: float("inf") for k in variants}
@@ -53,7 +53,7 @@ for A, N in shapes:
             best[name] = min(best[name], e0.elapsed_time(e1) / 5)
     _lib.set_tuning("k1_flat", 1)
     _lib.set_tuning("k1_rowphase", 0)
-    nbytes = {"default": 5, "rowphase": 5, "anyA": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
+    nbytes = {"default": 5, "rowphase": 5, "element": 5, "default_dist_only": 4, "default_mask_only": 1, "fill": 5}
     row = {"A": A, "N": N, "B": B, "kernel": _lib.k1_plan(B, N, A)["kernel"], **{k: {"ms": round(v, 4), "TBps": round(B * N * N * A * A * nbytes[k] / v / 1e9, 3)}
                                      for k, v in best.items()}}
     rows.append(row)

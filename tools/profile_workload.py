@@ -4,7 +4,7 @@
     k3      BASELINE config 3 (B=128, N_res=512): pairwise_dihedrals (2,2) CA,CB|CA,CB and (3,1) N,CA,CB|CB,
             pairwise_planar_angles (2,1) CA,CB|CB, and the fused inter_residue_geometry
     k1a     K1 at atom14 (N=256) and atom37 (N=128), ~8 GB of output each: default dispatch (fixed-A flat pattern
-            kernel) and the any-A flat kernel (k1_flat=3)
+            kernel / row-phase kernel) and the row-phase kernel forced (k1_rowphase=1)
     k1      the headline K1 launch (B=64, N=512, A=15)
     k1s     K1 at the small atom counts, ~4 GB of output each: (A, N) = (5, 512), (5, 500), (5, 501), (3, 501), (1, 512),
             (2, 512) through the default dispatch (row-phase kernel)
@@ -49,10 +49,10 @@ elif what == "k1a":
         xyz, mask = synth(B, N, A)
         d = torch.empty(B, N, N, A, A, device="cuda")
         m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
-        for flat in (1, 3):
-            _lib.set_tuning("k1_flat", flat)
+        for rp in (0, 1):
+            _lib.set_tuning("k1_rowphase", rp)
             repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
-        _lib.set_tuning("k1_flat", 1)
+        _lib.set_tuning("k1_rowphase", 0)
         del xyz, mask, d, m
 elif what == "k1s":
     for A, N in ((5, 512), (5, 500), (5, 501), (3, 501), (1, 512), (2, 512)):
