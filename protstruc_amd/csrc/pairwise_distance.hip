@@ -1509,17 +1509,19 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     // short rows: 2 or 4 row groups of 128 / 64 lanes (every lane still takes ~32 rows), see the kernel
     const int lpg_log2 = nslots <= 128 ? 6 : (nslots <= 256 ? 7 : 8);
     const int G = 256 >> lpg_log2, tile_slots = T::SPL << lpg_log2;
-#ifndef PS_RP_ROWS
-#define PS_RP_ROWS 32      // rows per lane and workgroup (A/B builds only: tools/k1_ab_libs.py)
-#endif
-    const int n_ichunks = (rows + PS_RP_ROWS * G - 1) / (PS_RP_ROWS * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= 32 G rows, balanced
+    // Rows per lane (= rows per workgroup / G).  Short-lived workgroups suit the store stream (the fewer bytes a
+    // workgroup writes, the better slow-class allocations absorb it), a workgroup's set-up -- staging, the per-lane index
+    // decode -- wants to be amortised.  Same-process sweeps of 4 .. 32 rows on two boxes (profiles/
+    // r03_k1_ab_rowphase_tiling.log, r03_k1_rowphase_rows_per_lane.log): the compile-time counts (cheap decode) peak at
+    // 8-16 rows (A = 5, N = 501: 5.6-6.3 TB/s against 3.7-5.2 with 32), A = 1 / 2, whose rows are short, at 16-24; the
+    // run-time even counts at 8-16; the run-time odd counts (seven-element windows, run-time divisions) at 32.
+    // cfg.rows_per_block > 1 overrides (A/B runs).
+    const int rpl = g.rows_per_block > 1 ? g.rows_per_block : (ACT > 0 ? (ACT <= 2 ? 16 : 12) : (ACT == 0 ? 12 : 32));
+    const int n_ichunks = (rows + rpl * G - 1) / (rpl * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= rpl * G rows, balanced
+    // Tiles: FULL tiles of tile_slots and a short last one.  (Balanced tiles leave the last wave of EVERY workgroup idle
+    // for a pass: A = 5, N = 500 ran 4.4 against 5.2 TB/s.)
     const int n_tiles = (nslots + tile_slots - 1) / tile_slots;
-    int spt = (nslots + n_tiles - 1) / n_tiles;          // slots per tile-row, balanced over the tiles, whole waves
-    spt = ((spt + 63) / 64) * 64;
-    if (spt > tile_slots) spt = tile_slots;
-#ifdef PS_RP_UNBALANCED   // A/B builds only: full tiles and a short last one instead of balanced tiles
-    spt = tile_slots;
-#endif
+    const int spt = tile_slots;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;

@@ -1,15 +1,18 @@
 #!/usr/bin/python3
 """Same-process A/B of two BUILDS of the library (e.g. the product .so against one compiled with an extra -D):
-both are loaded with ctypes, and ps_pairwise_distance_f32 of each is timed in interleaved rounds on the same
-buffers.  Usage: python3 tools/k1_ab_libs.py libA.so libB.so [A:N ...]   (default shapes: 37:128 25:128 14:256)"""
+all are loaded with ctypes, and ps_pairwise_distance_f32 of each is timed in interleaved rounds on the same
+buffers.  Usage: python3 tools/k1_ab_libs.py libA.so libB.so [libC.so ...] [A:N ...]   (default shapes: 37:128 25:128
+14:256); every argument ending in .so is a library, the others are shapes; the first library is the bit reference."""
 import ctypes
 import os
 import sys
 
 import torch
 
-libs = [ctypes.CDLL(os.path.abspath(p)) for p in sys.argv[1:3]]
-shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[3:]] or [(37, 128), (25, 128), (14, 256)]
+paths = [a for a in sys.argv[1:] if a.endswith(".so")]
+libs = [ctypes.CDLL(os.path.abspath(p)) for p in paths]
+names = [os.path.basename(p).replace("libprotstruc_hip", "product").replace("lib_", "").replace(".so", "") for p in paths]
+shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:] if not a.endswith(".so")] or [(37, 128), (25, 128), (14, 256)]
 vp, i32 = ctypes.c_void_p, ctypes.c_int
 for lib in libs:
     lib.ps_pairwise_distance_f32.restype = i32
@@ -29,8 +32,8 @@ for A, N in shapes:
     outs = []
     for lib in libs:
         run(lib); torch.cuda.synchronize(); outs.append((d.clone(), m.clone()))
-    same = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    best = [float("inf")] * 2
+    same = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+    best = [float("inf")] * len(libs)
     for rnd in range(4):
         for k, lib in enumerate(libs):
             run(lib); run(lib)
@@ -40,5 +43,6 @@ for A, N in shapes:
             e1.record(); torch.cuda.synchronize()
             best[k] = min(best[k], e0.elapsed_time(e1) / 5)
     nb = B * N * N * A * A * 5
-    print(f"A={A:3d} N={N:4d} B={B:4d}  libA {nb/best[0]/1e9:5.2f} TB/s   libB {nb/best[1]/1e9:5.2f} TB/s   same bits: {same}", flush=True)
+    print(f"A={A:3d} N={N:4d} B={B:4d}  " + "  ".join(f"{n} {nb / b / 1e9:5.2f}" for n, b in zip(names, best)) +
+          f"  TB/s   same bits: {same}", flush=True)
     del xyz, mask, d, m, outs
