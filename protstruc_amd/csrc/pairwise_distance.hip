@@ -1636,7 +1636,7 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
 #define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);
         switch (A) {
             PS_K1_RP(1) PS_K1_RP(2) PS_K1_RP(3) PS_K1_RP(5) PS_K1_RP(6) PS_K1_RP(7) PS_K1_RP(9) PS_K1_RP(10) PS_K1_RP(11)
-            PS_K1_RP(12) PS_K1_RP(13)
+            PS_K1_RP(12) PS_K1_RP(13) PS_K1_RP(15)   // (15: only with cfg.rowphase = 1 -- the A/B against the pattern kernels)
             default: break;
         }
 #undef PS_K1_RP

@@ -38,8 +38,15 @@ cfgs = {
     "flat 16p +8KB": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_lds_pad_kb=8),
     "flat 16p x2": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=2),
     "flat 16p x4": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=4),
+    # round 3: the row-phase kernel at A = 15 (k1_rowphase = 1), rows per lane 4 .. 32: 8 KB + 2 KB pieces of that many rows
+    "rowphase r4": dict(k1_rowphase=1, k1_rows_per_block=4), "rowphase r6": dict(k1_rowphase=1, k1_rows_per_block=6),
+    "rowphase r8": dict(k1_rowphase=1, k1_rows_per_block=8), "rowphase r12": dict(k1_rowphase=1, k1_rows_per_block=12),
+    "rowphase r16": dict(k1_rowphase=1, k1_rows_per_block=16), "rowphase r32": dict(k1_rowphase=1, k1_rows_per_block=32),
 }
-DEFAULTS = dict(k1_rows_per_block=1, k1_jt=0, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1)
+DEFAULTS = dict(k1_rows_per_block=1, k1_jt=0, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1,
+                k1_rowphase=0)
+if len(sys.argv) > 2:      # a comma-separated subset of configuration names
+    cfgs = {k: v for k, v in cfgs.items() if any(k.startswith(p) for p in sys.argv[2].split(","))}
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
         for _ in range(nbuf)]
 
