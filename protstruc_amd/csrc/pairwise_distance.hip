@@ -1467,7 +1467,8 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
                    int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     constexpr int JT = RowTile<A>::JT;
     const int rows = row_end - row_begin;
-    const int IR = rows < 32 ? rows : 32;              // 32 rows x 8 KB + 2 KB of mask = 320 KB per workgroup at most
+    const int irmax = g.rows_per_block > 1 ? g.rows_per_block : 32;   // (cfg.rows_per_block > 1: A/B runs)
+    const int IR = rows < irmax ? rows : irmax;        // 32 rows x 8 KB + 2 KB of mask = 320 KB per workgroup at most
     const int n_tiles = (N + JT - 1) / JT, n_ichunks = (rows + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;

@@ -137,3 +137,15 @@ def test_shard_rows_partition():
             assert cuts[0][0] == 0 and cuts[-1][1] == n
             assert all(cuts[r][1] == cuts[r + 1][0] for r in range(world - 1))
             assert max(hi - lo for lo, hi in cuts) - min(hi - lo for lo, hi in cuts) <= 1
+
+
+def test_native_comm_needs_a_gpu_and_allgather_rows_validates():
+    """The native communicator is bound to the device of the buffers it gathers: a CPU device is refused before any
+    collective or RCCL call; allgather_rows refuses non-contiguous input and unknown implementations."""
+    import pytest
+    import torch
+    from protstruc_amd import distributed as D
+    with pytest.raises(ValueError, match="needs a GPU"):
+        D.native_comm(device="cpu")
+    with pytest.raises(ValueError, match="contiguous"):
+        D.allgather_rows(torch.zeros(2, 4, 6)[:, :, ::2])

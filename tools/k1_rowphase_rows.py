@@ -14,6 +14,8 @@ shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [
     (1, 512), (1, 501), (2, 512), (3, 512), (3, 500), (5, 512), (5, 500), (5, 501), (7, 500), (10, 500), (13, 250), (20, 125),
     (33, 100), (25, 128), (37, 128), (64, 64)]
 ROWS = (0, 4, 6, 8, 12, 16, 24, 32)      # 0 = the library's default
+if os.environ.get("K1_ROWS"):
+    ROWS = tuple(int(v) for v in os.environ["K1_ROWS"].split(","))
 g = torch.Generator().manual_seed(0)
 print("rows per lane:      " + "  ".join(f"{'dflt' if r == 0 else r:>5}" for r in ROWS) + "   fill   (TB/s)")
 for A, N in shapes:
