@@ -1467,8 +1467,12 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
                    int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
     constexpr int JT = RowTile<A>::JT;
     const int rows = row_end - row_begin;
-    const int irmax = g.rows_per_block > 1 ? g.rows_per_block : 32;   // (cfg.rows_per_block > 1: A/B runs)
-    const int IR = rows < irmax ? rows : irmax;        // 32 rows x 8 KB + 2 KB of mask = 320 KB per workgroup at most
+    // Rows per workgroup: 6 (60 KB of output per workgroup).  Round 2 used 32; same-process sweeps of 2 .. 32 rows on two
+    // boxes (profiles/r03_k1_rowtile_rows_per_workgroup.log) have 3-6 rows 3-12 % ahead of 32 at every shape (A = 4,
+    // N = 500: 6.5-6.8 against 6.0 TB/s), 6 being the best or within 3 % of it also for short structures (N = 100 / 128),
+    // where 2-4 rows lose.  cfg.rows_per_block > 1 overrides (A/B runs).
+    const int irmax = g.rows_per_block > 1 ? g.rows_per_block : 6;
+    const int IR = rows < irmax ? rows : irmax;
     const int n_tiles = (N + JT - 1) / JT, n_ichunks = (rows + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
