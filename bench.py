@@ -26,6 +26,9 @@ outputs are resident in HBM before the timed region.
   (``config4_kernel_only_pairs_per_s``, ``config4_kernel_only_efficiency_vs_1gpu``,
   ``config4_allgather_ingress_GBps_per_rank`` next to ``config4_xgmi_ingress_bound_GBps_per_rank``,
   ``config4_end_to_end_ms``) and every detail is under "rowshard_allgather".
+  One gather implementation failing while the other completes and the gathered
+  matrix checks out is a top-level ``rowshard_warning`` (exit 0); a failed check
+  or no working gather is ``rowshard_error`` (exit 4).
   Time budget: the watchdog allows that section 420 s (at P = 2 three gathers of
   0.49 s or more per implementation plus warm-ups, 151 GB of allocations and the
   checks take well under a minute); the self-launcher gives the whole run 570 s,
@@ -42,7 +45,11 @@ measured with HIP events on the launch stream inside the timed region.
 (``ps_k1_plan_f32``), and ``roofline.buffer_fill_GBps`` is the rate at which
 ``torch.fill_`` writes the SAME two output buffers, measured after the timed
 region: MI355X allocations come in a faster and a slower class,
-and this is how the line shows which one this run drew.
+and this is how the line shows which one this run drew; ``roofline.allocation_lottery``
+(N = 1, informational, measured after everything else) times the same kernel on
+four fresh allocations of the process.  ``roofline.wall_minus_kernel_ms_per_step``
+is the host-side gap between the wall clock of the timed region and the kernels'
+own event time (timing events are created before the timed region).
 ``cpu_baseline`` (N = 1 only) times the CPU oracle -- the same ATen op sequence
 as the reference -- on a bounded sample of the same workload on the host cores,
 at the default thread count and at one thread.
