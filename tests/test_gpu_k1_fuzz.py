@@ -1,6 +1,8 @@
 """Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, fixed-A flat, row-tile, row-phase) against its two simple kernels
 (slot-decode for A = 15, element-per-lane otherwise): random shapes, row ranges, compact / in-place outputs, chunk
-counts per workgroup and both square-root modes; outputs sit inside sentinel-filled buffers.  -m gpu."""
+counts per workgroup and both square-root modes; outputs sit inside sentinel-filled buffers; every eighth trial is also
+held to the reference's formula evaluated by ATen on the device (an implementation that shares nothing with the kernels).
+-m gpu."""
 import numpy as np
 import pytest
 import torch
@@ -74,6 +76,14 @@ def test_k1_fast_kernels_differential_fuzz():
             got_m = m if compact else m[:, r0:r1]
             assert _same_floats(got_d.contiguous(), ref_d[:, r0:r1].contiguous()), info
             assert torch.equal(got_m, ref_m[:, r0:r1]), info
+            if trial % 8 == 0 and B * N * N * A * A <= 4_000_000:
+                # and against an implementation that shares nothing with the kernels: the reference's formula evaluated by
+                # ATen on the device (differences, squares, sum, sqrt) and the mask as an outer AND
+                want = (xg[:, r0:r1, None, :, None, :] - xg[:, None, :, None, :, :]).square().sum(-1).sqrt()
+                ok = torch.isclose(got_d, want, rtol=2e-6, atol=1e-5) | (got_d.isnan() & want.isnan())
+                assert bool(ok.all()), info
+                mm = mask.cuda() if use_mask else torch.ones(B, N, A, dtype=torch.bool, device="cuda")
+                assert torch.equal(got_m, mm[:, r0:r1, None, :, None] & mm[:, None, :, None, :]), info
             assert (bd[:pad] == SENT).all() and (bd[pad + numel:] == SENT).all(), info
             assert (bm[:pad] == 7).all() and (bm[pad + numel:] == 7).all(), info
             if not compact:
