@@ -74,8 +74,8 @@ typedef struct ps_k1_config {
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
     int rowphase;         /* row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
-                             dispatch -- A <= 13 and every count without a fixed-A flat kernel; 1 also for A = 14, 15, 16, 24,
-                             25, 27, 32, 37 (A/B runs); 2 never (flat / any-A / element kernels instead) */
+                             dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel; 1 also for A = 14, 15, 16,
+                             24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead) */
     int experiment;       /* must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
                              run that writes WRONG values, +16 = fully unrolled group loop */

@@ -1490,7 +1490,7 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
 // Row-phase kernel: every atom count up to 64 other than 4, 8 (row-tile kernel) and 15; any N, any row range.  The small
 // counts are compile-time instantiations; the rest share the two run-time instantiations (even / odd A).  cfg.rowphase:
 // 0 = where it is the default (A <= 13, and the counts without a fixed-A flat kernel), 1 = every eligible count (A/B runs
-// against the fixed-A flat kernels), 2 = never (A/B runs against the flat / any-A kernels).
+// against the fixed-A flat and the A = 15 kernels), 2 = never (fixed-A flat / element kernels instead).
 bool rowphase_ct(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
 
 bool flatA_has(int A);

@@ -485,7 +485,7 @@ def test_k1_misaligned_output_buffers(SB):
 
 def test_k1_capi_argument_validation_streams_and_capture(SB):
     """The C entry point itself: invalid arguments are rejected before anything is launched (hipErrorInvalidValue = 1),
-    launches on different streams are independent, and the flat / any-A kernels are hipGraph-capturable."""
+    launches on different streams are independent, and the flat / row-phase kernels are hipGraph-capturable."""
     import ctypes
     from protstruc_amd import _lib, ops
     lib = _lib.load()
@@ -516,7 +516,7 @@ def test_k1_capi_argument_validation_streams_and_capture(SB):
     assert call(*(ok[:4] + (0,) + ok[5:])) == 0             # B = 0 is a no-op, not an error
     ref_d, ref_m = d.clone(), m.clone()
 
-    # two streams, two shapes (flat pattern kernel and any-A kernel), interleaved launches
+    # two streams, two shapes (flat pattern kernel and row-phase kernel), interleaved launches
     xyz5, mask5 = synth(32, 3, 33, A=5)
     x5, m5 = xyz5.cuda(), mask5.cuda()
     want5 = ops.pairwise_distance(x5, m5)
