@@ -302,7 +302,7 @@ def launch_ranks(n, argv):
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
-    deadline = time.time() + float(os.environ.get("PS_BENCH_LAUNCH_TIMEOUT", "570"))
+    deadline = time.time() + float(os.environ.get("PS_BENCH_LAUNCH_TIMEOUT", "570"))   # inside the driver's 600 s
     out0, codes, timed_out = b"", [], False
     for r, p in enumerate(procs):
         try:

@@ -1116,13 +1116,13 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
 // time, the column mask words are 64 bits wide).  Only the parity of A decides the code shape (one phase or four).
 template <int ACT>
 struct RowPhase {
-    static_assert(ACT >= -1 && ACT <= 31, "row-phase kernel: compile-time atom counts up to 31");
+    static_assert(ACT >= -1 && ACT <= 64, "row-phase kernel: atom counts up to 64");
     static constexpr bool PHASED = ACT > 0 ? ((ACT * ACT) % 4 != 0) : (ACT == -1);   // odd A: A*A = 1 (mod 4)
     static constexpr int W = PHASED ? 7 : 4;           // elements per slot whose column atoms a lane keeps
     static constexpr int W0 = PHASED ? 3 : 0;          // window element of row element 4 s
     static constexpr int SPL = 2;                      // slots per lane per row
     static constexpr int TS = 256 * SPL;               // slots per tile-row at most (8 KB of distances)
-    typedef typename std::conditional<(ACT > 0), uint32_t, unsigned long long>::type bits_t;   // A mask bits of a residue
+    typedef typename std::conditional<(ACT > 0 && ACT < 32), uint32_t, unsigned long long>::type bits_t;   // A mask bits of a residue
 };
 
 // column residues a tile's elements can touch (host and device use the same formula for the LDS carve)
@@ -1491,8 +1491,6 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
 // counts are compile-time instantiations; the rest share the two run-time instantiations (even / odd A).  cfg.rowphase:
 // 0 = where it is the default (A <= 13, and the counts without a fixed-A flat kernel), 1 = every eligible count (A/B runs
 // against the fixed-A flat and the A = 15 kernels), 2 = never (fixed-A flat / element kernels instead).
-bool rowphase_ct(int A) { return A == 1 || A == 2 || A == 3 || (A >= 5 && A <= 7) || (A >= 9 && A <= 13); }
-
 bool flatA_has(int A);
 
 bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
@@ -1641,7 +1639,8 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
 #define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);
         switch (A) {
             PS_K1_RP(1) PS_K1_RP(2) PS_K1_RP(3) PS_K1_RP(5) PS_K1_RP(6) PS_K1_RP(7) PS_K1_RP(9) PS_K1_RP(10) PS_K1_RP(11)
-            PS_K1_RP(12) PS_K1_RP(13) PS_K1_RP(15)   // (15: only with cfg.rowphase = 1 -- the A/B against the pattern kernels)
+            PS_K1_RP(12) PS_K1_RP(13) PS_K1_RP(25) PS_K1_RP(37)   // (25: the reference's own test count; 37: atom37)
+            PS_K1_RP(15)                                          // (only with cfg.rowphase = 1: the A/B against the pattern kernels)
             default: break;
         }
 #undef PS_K1_RP

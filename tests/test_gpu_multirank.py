@@ -17,7 +17,7 @@ from tests import conftest
 pytestmark = pytest.mark.gpu
 
 
-def _verdict(name, timeout=420):
+def _verdict(name, timeout=330):
     code, log = conftest.wait_rehearsal(name, timeout)
     try:
         with open(conftest.REHEARSALS[name]["out"]) as f:
@@ -58,7 +58,7 @@ def test_bench_gpus2_self_launch_as_the_driver_invokes_it():
     (the command form the driver uses for N > 1): the parent starts two rank processes of itself, relays ONE JSON line
     and exits 0; the headline check and the check after the gather are both ok and the strong-scaling keys are
     top-level."""
-    code, log = conftest.wait_rehearsal("bench_gpus2", 900)
+    code, log = conftest.wait_rehearsal("bench_gpus2", 750)
     out = open(conftest.REHEARSALS["bench_gpus2"]["stdout"]).read()
     lines = [ln for ln in out.splitlines() if ln.strip()]
     assert code == 0, (code, out[-500:], log[-3000:])
