@@ -13,6 +13,8 @@ from protstruc_amd import _lib, ops
 shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [
     (1, 512), (1, 501), (2, 512), (3, 512), (3, 500), (5, 512), (5, 500), (5, 501), (7, 500), (10, 500), (13, 250), (20, 125),
     (33, 100), (25, 128), (37, 128), (64, 64)]
+if os.environ.get("K1_ROWPHASE"):         # 1: the row-phase kernel also where a fixed-A flat kernel is the default
+    _lib.set_tuning("k1_rowphase", int(os.environ["K1_ROWPHASE"]))
 ROWS = (0, 4, 6, 8, 12, 16, 24, 32)      # 0 = the library's default
 if os.environ.get("K1_ROWS"):
     ROWS = tuple(int(v) for v in os.environ["K1_ROWS"].split(","))
