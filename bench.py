@@ -5,7 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Both forms work for N > 1.  Started WITHOUT a launcher (WORLD_SIZE unset), ``bench.py --gpus N`` is its own launcher:
+Both forms work for N > 1.  The control plane (barriers, max over ranks, verdict exchange) is a gloo group; only the
+all-gather of the row-shard section runs on RCCL (its own group), so the headline line does not depend on RCCL.  Started WITHOUT a launcher (WORLD_SIZE unset), ``bench.py --gpus N`` is its own launcher:
 the parent -- which never touches the GPU -- starts N fresh rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE /
 MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment, one rank per GPU over RCCL), relays rank 0's single JSON line
 to its own stdout and exits with the largest child exit code.  It never replaces itself with another program.
@@ -193,7 +194,7 @@ def check_outputs(xyz, mask, out_d, out_m, n_blocks=64, seed=7):
     return fails
 
 
-def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, steps=2):
+def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, steps=2, group=None):
     """BASELINE config 4: residue-sharded K1 into a full-size buffer + all-gather (native RCCL and torch paths),
     each part timed with HIP events on the launch stream; max over ranks.  Every verdict (an exception in a step, a
     failed check) is exchanged between the ranks before anyone acts on it, so all ranks take the same path and
@@ -250,8 +251,8 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
     ingress = total_bytes * (world - 1) / world
     for impl in impls:
         def gather_only(impl=impl):
-            D.allgather_rows(out_d, impl=impl)
-            D.allgather_rows(out_m, impl=impl)
+            D.allgather_rows(out_d, group, impl=impl)
+            D.allgather_rows(out_m, group, impl=impl)
         key = f"allgather_{impl}"
         try:
             res[key + "_ms"] = timed(gather_only, steps)
@@ -267,7 +268,7 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
         raise RuntimeError("no all-gather implementation completed: " +
                            "; ".join(f"{k}: {v}" for k, v in res.items() if k.endswith("_error")))
     # end to end with the implementation that worked best (normally the native one)
-    e2e = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather=True, impl=res["allgather_best_impl"],
+    e2e = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, group=group, gather=True, impl=res["allgather_best_impl"],
                                                      out_dist=out_d, out_mask=out_m)
     res["end_to_end_impl"] = res["allgather_best_impl"]
     res["end_to_end_ms"] = timed(e2e, steps)
@@ -277,7 +278,8 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
     fails = check_outputs(xyz, mask, out_d, out_m, n_blocks=128, seed=11 + rank)
     all_fails = [f"rank {r}: {f}" for r, fl in enumerate(all_ranks(fails)) for f in fl]
     res["check_after_gather"] = "ok" if not all_fails else all_fails
-    recompute = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, gather="recompute", out_dist=out_d, out_mask=out_m)
+    recompute = lambda: D.pairwise_distance_matrix_sharded(xyz, mask, group=group, gather="recompute", out_dist=out_d,
+                                                           out_mask=out_m)
     res["full_matrix_recomputed_per_rank_ms"] = timed(recompute, steps)
     # strong scaling of the kernel alone: the same matrix written by ONE GPU (the recompute form, timed just above in
     # this very run) against 1/P of its rows per GPU
@@ -405,8 +407,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        kw = {"device_id": dev} if args.backend == "nccl" else {}
-        dist.init_process_group(args.backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
+        # Control plane (barriers, object collectives, max over ranks) on gloo: the headline measurement needs nothing
+        # from RCCL, so a communicator problem on a node surfaces in the row-shard section below (watchdog, loud error)
+        # and cannot take the headline line with it.  The data plane -- the all-gather -- gets its own RCCL group.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")     # one node: loopback (the hostname may not resolve)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
 
     def max_over_ranks(values):
         """Element-wise max of a list of floats over all ranks (object collective: works on any backend)."""
@@ -588,7 +593,11 @@ def main():
         out_d = out_m = None
         torch.cuda.empty_cache()
         try:
-            rs = rowshard_allgather(dev, rank, world, max_over_ranks, args.backend, shared_gpu=world > n_dev)
+            data_group = None        # gloo rehearsals: the control group carries the data as well
+            if args.backend != "gloo":
+                data_group = dist.new_group(backend=args.backend, timeout=datetime.timedelta(seconds=300), device_id=dev)
+            rs = rowshard_allgather(dev, rank, world, max_over_ranks, args.backend, shared_gpu=world > n_dev,
+                                    group=data_group)
             result["rowshard_allgather"] = rs
             # the strong-scaling figures of the north star, where a parser finds them
             result["config4_workload"] = rs["workload"]
