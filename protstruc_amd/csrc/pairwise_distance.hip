@@ -1094,16 +1094,16 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
     }
 }
 
-// ---- row-phase kernel: small atom counts, ANY length (A <= 13 without a multiple-of-4 count; A = 1, 2 included) ----
+// ---- row-phase kernel: every atom count up to 64 that has no better kernel, ANY length ----
 // The column-stationary idea of the row-tile kernels without their alignment conditions.  A row run of the distance plane
 // starts (R * N * A*A) mod 4 floats past a 16-byte boundary (R = absolute row of the buffer); for even A that is always 0,
 // for odd A it is one of four PHASES fixed by R mod 4.  Slots are cut on the ABSOLUTE 16-byte grid: slot s of a row with
 // phase ph holds row elements 4 s - ph .. 4 s - ph + 3.  A lane owns slot s (two of them, 256 apart) of every row of its
 // workgroup, keeps the column atoms of the SEVEN elements 4 s - 3 .. 4 s + 3 in registers (four when there is one phase
 // only), and -- the phase being uniform over the workgroup -- takes one of four straight-line arms per row that uses the
-// window 3 - ph .. 6 - ph of them.  So, unlike the phased variant of the odd row-tile kernel this replaces (rows of one
-// residue class of R mod 4 per workgroup, three launches' worth of strided row streams in flight), a workgroup writes IR
-// CONSECUTIVE rows: one sequential stream per workgroup, as in the aligned kernels.
+// window 3 - ph .. 6 - ph of them.  So, unlike the phased variant of round 2's odd row-tile kernel that this replaced (rows
+// of one residue class of R mod 4 per workgroup), a workgroup writes IR CONSECUTIVE rows.  It also replaced that round's
+// small and odd fixed-A flat kernels, k1_mask_rows and the any-A flat kernel (same-process A/Bs in profiles/r03_*).
 //   * tiles are cut in slot space, so a slot never belongs to two tiles; the only shared slots are the one that holds a
 //     row's end and the next row's start, which both rows write element-wise (their own elements only);
 //   * the mask plane rides in the same loop: the four mask bytes of a slot's elements are one aligned dword store (byte
@@ -1111,7 +1111,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
 //   * the four row atoms of a slot's elements are LDS reads (broadcasts: many lanes read the same few atoms) whose
 //     fourth component carries the atom's mask bit; for A = 1 there is a single row atom, read once per row;
 //   * everything per row (phase, row pointer, LDS row address) is wave-uniform and rides in SGPRs.
-// ACT > 0: the atom count is the compile-time constant ACT (the small counts: index decode with constant divisors);
+// ACT > 0: the atom count is the compile-time constant ACT (the small counts, 25 and atom37: index decode with constant divisors);
 // ACT = 0 / -1: a RUN-TIME even / odd atom count up to 64 (same kernel; the decode -- once per workgroup -- divides at run
 // time, the column mask words are 64 bits wide).  Only the parity of A decides the code shape (one phase or four).
 template <int ACT>
