@@ -102,7 +102,7 @@ void ps_k1_config_default(ps_k1_config* cfg);
  * Limits (hipErrorInvalidValue beyond them): B * out_rows * N < 2^32 pairs per launch for the flat kernels
  * (A = 15 at any N >= 16 that is not a multiple of 16; A = 14, 16, 24, 32), 2^31 workgroups for the pattern, row-tile
  * and row-phase kernels (the latter also N * A * A <= 2^28); B <= 65535 only for the two simple kernels that put the
- * structure on grid.z (A = 15 at N < 16 or on unaligned planes; A > 64; unaligned planes).  K2 / K3 run on 1-D grids:
+ * structure on grid.z (A = 15 on unaligned planes or with variant = 1; A > 64; unaligned planes).  K2 / K3 run on 1-D grids:
  * any batch size up to 2^31 workgroups per launch.
  * Arithmetic: sqrt((dx*dx + dy*dy) + dz*dz) in fp32 without contraction; the square
  * root is the hardware instruction (exact for 85 % of inputs, 1 ulp off otherwise)

@@ -24,7 +24,7 @@
 // Three A = 15 kernels share that scheme.  Shapes with N % 16 == 0 take the "pattern" kernel (fixed per-lane
 // decode, row atoms in registers); any other N >= 16 takes the "flat pattern" kernel (the same fixed decode laid
 // over the flat pair axis, so rows need no alignment at all); the slot-decode kernel described above remains for
-// N < 16, unaligned planes and as the bit-identity cross-check in the tests.
+// unaligned planes and as the bit-identity cross-check in the tests (N < 16 takes the row-phase kernel).
 //
 // Other atom counts: A = 4, 8 the row-tile kernel; A = 14, 16, 24, 32 the fixed-A flat pattern kernel; every other
 // A <= 64 the row-phase kernel (column atoms stationary in registers, any N; compile-time instantiations for the small
@@ -1496,8 +1496,9 @@ bool flatA_has(int A);
 bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
     if (g.variant != 0 || g.flat != 1 || g.rowphase == 2) return false;
     if (A < 1 || A > 64 || A == 4 || A == 8) return false;
-    if (A == 15 && g.rowphase != 1) return false;                      // A = 15 has its own kernels
-    if (flatA_has(A) && g.rowphase != 1) return false;                 // even counts with a fixed-A flat kernel
+    if (A == 15 && g.rowphase != 1 && N >= 16) return false;           // A = 15 has its own kernels from N = 16 on; batches of
+                                                                       // shorter peptides take this kernel (1-D grid: any B)
+    if (A != 15 && flatA_has(A) && g.rowphase != 1) return false;      // even counts with a fixed-A flat kernel
     if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
@@ -1640,7 +1641,7 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         switch (A) {
             PS_K1_RP(1) PS_K1_RP(2) PS_K1_RP(3) PS_K1_RP(5) PS_K1_RP(6) PS_K1_RP(7) PS_K1_RP(9) PS_K1_RP(10) PS_K1_RP(11)
             PS_K1_RP(12) PS_K1_RP(13) PS_K1_RP(25) PS_K1_RP(37)   // (25: the reference's own test count; 37: atom37)
-            PS_K1_RP(15)                                          // (only with cfg.rowphase = 1: the A/B against the pattern kernels)
+            PS_K1_RP(15)                                          // (N < 16; N >= 16 only with cfg.rowphase = 1: the A/B against the pattern kernels)
             default: break;
         }
 #undef PS_K1_RP

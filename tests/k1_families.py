@@ -8,13 +8,15 @@ oracle.  Together: every kernel family is reached by a shape that is held to the
 Entry: (B, N, A, (row_begin, row_end) or None, compact, {K1 tuning overrides}, expected family)."""
 
 FAMILY_SHAPES = [
-    # A = 15: pattern (N % 16 == 0), flat pattern (any other N >= 16), slot-decode (N < 16, or the simple variant)
+    # A = 15: pattern (N % 16 == 0), flat pattern (any other N >= 16), slot-decode (the simple variant; N < 16 without the
+    # row-phase kernel, which is the default there)
     (2, 64, 15, None, False, {}, "pattern"),
     (2, 256, 15, (64, 128), False, {}, "pattern"),
     (3, 50, 15, None, False, {}, "flat"),
     (2, 37, 15, (5, 30), True, {}, "flat"),
     (2, 64, 15, None, False, {"k1_flat": 2, "k1_flat_fl_log2": 5}, "flat"),
-    (2, 12, 15, None, False, {}, "slot_decode"),
+    (2, 12, 15, None, False, {"k1_rowphase": 2}, "slot_decode"),
+    (3, 12, 15, (2, 9), False, {}, "rowphase"),
     (2, 48, 15, None, False, {"k1_variant": 1}, "slot_decode"),
     # fixed-A flat pattern kernels (the even counts 14, 16, 24, 32; A = 15 with k1_flat = 4 as the cross-check)
     (2, 40, 14, None, False, {}, "flatA"),
