@@ -1588,7 +1588,7 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4 || g.flat == 3) return false;
     if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < 0 || g.lds_pad_kb > 120) return false;
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
-    if (g.jt != 0 && g.jt != 64 && g.jt != 128) return false;
+    if (g.jt != 0 && g.jt != 32 && g.jt != 64 && g.jt != 128) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
     if (g.rowphase < 0 || g.rowphase > 2) return false;
 #ifdef PS_EXPERIMENTS
@@ -1683,6 +1683,9 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         if (jt == 128)
             return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,
                                    out_row_origin, go);
+        if (jt == 32)
+            return launch_a15<32>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
+                                  go);
         return launch_a15<64>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
                               go);
     }

@@ -152,26 +152,36 @@ _K1_LAUNCH = _k1_launch_entry
 # tile.  What the second measurement on 6 + 8 buffers showed (profiles/r02_k1_ab_buffers.log): fast buffers like the
 # 64-residue tile + 8 KB best (7.1-7.2 TB/s against 7.0), slow buffers a hard cap of 2 workgroups per CU (64-residue
 # tile + 36 KB: 6.1 TB/s on EVERY buffer, against 5.9-6.0 for everything else on a slow one and 7.0+ on a fast one).
+# Round 3 added the 32-residue tile (36 KB of contiguous output per short-lived workgroup) with 6 and with 4 workgroups
+# per CU: on 8 + 8 buffers of two boxes (profiles/r03_k1_ab_pattern_small_tiles_residency_caps*.log) "jt32 + 18 KB" is
+# within +-3 % of the default on fast buffers and 2-4 % ahead on slow ones, "jt32 + 24 KB" is 5-8 % ahead on slow and
+# medium buffers (6.3-6.6 TB/s, the best seen there) and 5-7 % behind on fast ones -- which is what a tuner is for.
 _K1_CANDIDATE_PATTERN = (
     {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 0},
     {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 64},
+    {"rows_per_block": 1, "lds_pad_kb": 18, "jt": 32},
+    {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 64},
     {"rows_per_block": 1, "lds_pad_kb": 0, "jt": 0},
     {"rows_per_block": 2, "lds_pad_kb": 0, "jt": 0},
 )
 # flat kernel (any other N >= 16): chunks per workgroup, KB of idle LDS
+# (round 3: 32-pair chunks -- 36 KB per short-lived workgroup, 4 workgroups per CU -- run 6.1-6.3 TB/s on every buffer:
+# 3-5 % ahead of the 128-pair default on slow buffers, 13 % behind on fast ones; profiles/r03_k1_ab_small_granule.log)
 _K1_CANDIDATE_FLAT = (
-    {"flat_cpw": 1, "flat_lds_pad_kb": 0},
-    {"flat_cpw": 1, "flat_lds_pad_kb": 8},
-    {"flat_cpw": 2, "flat_lds_pad_kb": 0},
-    {"flat_cpw": 4, "flat_lds_pad_kb": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 8, "flat_fl_log2": 0},
+    {"flat_cpw": 2, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
+    {"flat_cpw": 4, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 5},
 )
 
 
 def _cand_label(c) -> str:
     if "rows_per_block" in c:
         return f"{c['rows_per_block']}row" + (f"+{c['lds_pad_kb']}KB" if c["lds_pad_kb"] else "") + (f" jt{c['jt']}" if c["jt"] else "")
-    return f"{c['flat_cpw']}chunk" + (f"+{c['flat_lds_pad_kb']}KB" if c["flat_lds_pad_kb"] else "")
+    return f"{c['flat_cpw']}chunk" + (f"+{c['flat_lds_pad_kb']}KB" if c["flat_lds_pad_kb"] else "") + \
+        (f" {1 << c['flat_fl_log2']}pairs" if c.get("flat_fl_log2") else "")
 
 
 def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False) -> None:

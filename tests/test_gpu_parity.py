@@ -240,7 +240,7 @@ def test_k1_store_policy_variants_agree(SB):
     nt0, rows0, var0, jt0 = (_lib.get_tuning(k) for k in ("k1_store_nt", "k1_rows_per_block", "k1_variant", "k1_jt"))
     try:
         for var in (0, 1):          # pattern kernel / slot-decode kernel
-            for jt in (0, 64, 128):
+            for jt in (0, 32, 64, 128):
                 for nt in (0, 1):
                     for rows in (1, 3, 8, 16):
                         _lib.set_tuning("k1_variant", var)
@@ -599,7 +599,7 @@ def test_k1_knobs_flipped_on_another_thread(SB):
         rng = np.random.default_rng(5)
         while not stop.is_set():
             _lib.set_tuning("k1_rows_per_block", int(rng.choice([1, 2, 3, 4, 8])))
-            _lib.set_tuning("k1_jt", int(rng.choice([0, 64, 128])))
+            _lib.set_tuning("k1_jt", int(rng.choice([0, 32, 64, 128])))
             _lib.set_tuning("k1_flat_cpw", int(rng.choice([1, 2, 5])))
             _lib.set_tuning("k1_xcd_remap", int(rng.integers(0, 2)))
             _lib.set_tuning("k1_store_nt", int(rng.integers(0, 2)))
@@ -716,7 +716,7 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         out_d, out_m = torch.empty_like(d0), torch.empty_like(m0)
         res = ops.autotune_pairwise_distance(xg, mg, out_d, out_m)
         assert res is not None and res["rows_per_block"] in (1, 2)
-        assert set(res["ms"]) == {ops._cand_label(c) for c in ops._K1_CANDIDATE_PATTERN} and len(res["ms"]) == 5
+        assert set(res["ms"]) == {ops._cand_label(c) for c in ops._K1_CANDIDATE_PATTERN} and len(res["ms"]) == 7
         assert _lib.get_tuning("k1_rows_per_block") == res["rows_per_block"]
         assert _lib.get_tuning("k1_lds_pad_kb") == res["lds_pad_kb"] and _lib.get_tuning("k1_jt") == res["jt"]
         assert torch.equal(out_d, d0) and torch.equal(out_m, m0)
@@ -742,11 +742,13 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         res2 = ops.autotune_pairwise_distance(x2, m2g, e1, f1)
         assert res2["flat_cpw"] in (1, 2, 4) and _lib.get_tuning("k1_flat_cpw") == res2["flat_cpw"]
         assert _lib.get_tuning("k1_flat_lds_pad_kb") == res2["flat_lds_pad_kb"]
+        assert res2["flat_fl_log2"] in (0, 5) and _lib.get_tuning("k1_flat_fl_log2") == res2["flat_fl_log2"]
+        assert len(res2["flat_ms"]) == len(ops._K1_CANDIDATE_FLAT)
         assert torch.equal(e0, e1) and torch.equal(f0, f1)
     finally:
         ops.set_implicit_autotune(False)
         for k, v in (("k1_rows_per_block", rows0), ("k1_lds_pad_kb", pad0), ("k1_jt", 0), ("k1_flat_cpw", 1),
-                     ("k1_flat_lds_pad_kb", 0)):
+                     ("k1_flat_lds_pad_kb", 0), ("k1_flat_fl_log2", 0)):
             _lib.set_tuning(k, v)
         ops._K1_TUNED.pop(xg.device, None)
         if saved_tuned is not None:

@@ -38,13 +38,29 @@ cfgs = {
     "flat 16p +8KB": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_lds_pad_kb=8),
     "flat 16p x2": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=2),
     "flat 16p x4": dict(k1_flat=2, k1_flat_fl_log2=4, k1_flat_cpw=4),
+    # round 3: the PATTERN kernel with 32- / 16-residue tiles: 36 / 18 KB of contiguous output per short-lived workgroup,
+    # consecutive workgroups at consecutive addresses (the store pattern of torch.fill_), 7 workgroups per CU
+    "pat jt32": dict(k1_jt=32, k1_lds_pad_kb=0), "pat jt32 +8KB": dict(k1_jt=32, k1_lds_pad_kb=8),
+    "pat jt32 noremap": dict(k1_jt=32, k1_lds_pad_kb=0, k1_xcd_remap=0), 
+    "pat jt64": dict(k1_jt=64, k1_lds_pad_kb=0),
+    # ... with residency caps (idle LDS): 8.4 KB + pad per workgroup of the 160 KB per CU
+    "cap jt32 +16KB": dict(k1_jt=32, k1_lds_pad_kb=16), "cap jt32 +24KB": dict(k1_jt=32, k1_lds_pad_kb=24),
+    "cap jt32 +32KB": dict(k1_jt=32, k1_lds_pad_kb=32), "cap jt32 +44KB": dict(k1_jt=32, k1_lds_pad_kb=44),
+    "cap jt32 +64KB": dict(k1_jt=32, k1_lds_pad_kb=64), "cap jt64 +16KB": dict(k1_jt=64, k1_lds_pad_kb=16),
+    "cap jt64 +24KB": dict(k1_jt=64, k1_lds_pad_kb=24), "cap jt128 +24KB": dict(k1_jt=128, k1_lds_pad_kb=24),
+    "fine jt32 +18KB": dict(k1_jt=32, k1_lds_pad_kb=18), "fine jt32 +20KB": dict(k1_jt=32, k1_lds_pad_kb=20),
+    "fine jt32 +22KB": dict(k1_jt=32, k1_lds_pad_kb=22), "fine jt32 +24KB": dict(k1_jt=32, k1_lds_pad_kb=24),
+    "fine jt32 +26KB": dict(k1_jt=32, k1_lds_pad_kb=26), "fine jt32 +28KB": dict(k1_jt=32, k1_lds_pad_kb=28),
+    "fine r2 jt32 +24KB": dict(k1_jt=32, k1_lds_pad_kb=24, k1_rows_per_block=2),
+    "fine r2 jt32 +16KB": dict(k1_jt=32, k1_lds_pad_kb=16, k1_rows_per_block=2),
+    "fine jt64 +20KB": dict(k1_jt=64, k1_lds_pad_kb=20), "fine jt64 +12KB": dict(k1_jt=64, k1_lds_pad_kb=12),
     # round 3: the row-phase kernel at A = 15 (k1_rowphase = 1), rows per lane 4 .. 32: 8 KB + 2 KB pieces of that many rows
     "rowphase r4": dict(k1_rowphase=1, k1_rows_per_block=4), "rowphase r6": dict(k1_rowphase=1, k1_rows_per_block=6),
     "rowphase r8": dict(k1_rowphase=1, k1_rows_per_block=8), "rowphase r12": dict(k1_rowphase=1, k1_rows_per_block=12),
     "rowphase r16": dict(k1_rowphase=1, k1_rows_per_block=16), "rowphase r32": dict(k1_rowphase=1, k1_rows_per_block=32),
 }
 DEFAULTS = dict(k1_rows_per_block=1, k1_jt=0, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1,
-                k1_rowphase=0)
+                k1_rowphase=0, k1_xcd_remap=1)
 if len(sys.argv) > 2:      # a comma-separated subset of configuration names
     cfgs = {k: v for k, v in cfgs.items() if any(k.startswith(p) for p in sys.argv[2].split(","))}
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
