@@ -144,15 +144,19 @@ def cpu_baseline(xyz, mask, budget_s=10.0, budget_1t_s=6.0):
     return out
 
 
-def load_traffic():
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/k1_traffic.json), or None."""
+def load_traffic(kernel):
+    """HBM bytes per launch of `kernel` (the name ps_k1_plan_f32 reports, e.g. "k1_pairdist_a15_pat<32>") from the committed
+    rocprofv3 PMC passes (profiles/k1_traffic.json), or None when that kernel was not in the passes."""
     p = os.path.join(ROOT, "profiles", "k1_traffic.json")
     try:
         with open(p) as f:
             t = json.load(f)
         if t.get("B") == B and t.get("N_res") == N_RES:
-            return t.get("hbm_bytes_per_launch"), ("profiles/k1_traffic.json: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes of "
-                                                    "this command, committed; NOT re-measured inside this run")
+            stem = kernel.rstrip(">")                      # "k1_pairdist_a15_pat<32" matches "k1_pairdist_a15_pat<32, false, 0, false>"
+            for name, e in t.get("kernels", {}).items():
+                if name == kernel or name.startswith(stem + ",") or name.startswith(stem + ">"):
+                    return e.get("hbm_bytes_per_launch"), (f"profiles/k1_traffic.json [{name}]: rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE "
+                                                           "passes of this command, committed; NOT re-measured inside this run")
     except (OSError, ValueError):
         pass
     return None, None
@@ -500,7 +504,7 @@ def main():
     pairs_per_step = B * N_RES * N_RES * world
     value = pairs_per_step * args.steps / elapsed
     achieved = B * N_RES * N_RES * BYTES_PER_PAIR / (kernel_ms_max * 1e-3) / 1e9
-    traffic, traffic_source = load_traffic()
+    traffic, traffic_source = load_traffic(plan["kernel"])
     result = {
         "metric": "residue-pairs/sec on pairwise_distance_matrix (B=64,N=512); % HBM roofline",
         "value": value, "unit": "residue-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

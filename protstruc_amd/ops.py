@@ -212,22 +212,27 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False
                        "ps_pairwise_distance_cfg_f32 (autotune)")
 
         # the first ~70 ms of GPU work after idle run ~2.5 % slow (clock ramp): warm up before timing anything,
-        # then time the candidates in interleaved rounds and keep each one's minimum
+        # then time the candidates in interleaved rounds
         t_end = time.perf_counter() + 0.12
         while time.perf_counter() < t_end:
             launch(0)
             torch.cuda.current_stream(device).synchronize()
-        timings = [float("inf")] * len(candidates)
-        for _ in range(3):
+        # Each candidate's figure is the MEDIAN over the rounds of a 3-launch mean, not its minimum: the small-tile
+        # candidates spread 3-4 % from launch to launch on fast buffers where the default spreads 1 %
+        # (profiles/r03_k1_launch_series.log), and a caller's steady state sees the mean.
+        rounds = [[] for _ in candidates]
+        for _ in range(5):
             for k in range(len(candidates)):
                 launch(k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 launch(k)
                 launch(k)
+                launch(k)
                 e1.record()
                 e1.synchronize()
-                timings[k] = min(timings[k], e0.elapsed_time(e1) / 2)
+                rounds[k].append(e0.elapsed_time(e1) / 3)
+        timings = [sorted(r)[len(r) // 2] for r in rounds]
         best = 0
         for k in range(1, len(candidates)):
             if timings[k] < timings[best] * 0.99:   # prefer the earlier candidate unless the gain is clear (1 %)

@@ -9,7 +9,9 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 240 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python3 bench.py --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err; echo "trace rc=$?"
 python3 tools/summarize_rocprof.py stats $O/trace $O/bench_kernel_stats.csv
-python3 tools/summarize_rocprof.py trace $O/trace $O/bench_kernel_trace_summary.json "k1_pairdist_a15_pat<128" 20
+# the kernel the timed launches took (the tuner may have picked another tile length than the default <128>)
+K=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['roofline']['kernel'].rstrip('>'))" $O/bench_traced.json)
+python3 tools/summarize_rocprof.py trace $O/trace $O/bench_kernel_trace_summary.json "$K" 20
 timeout -k 10 240 rocprofv3 --output-format csv --pmc WRITE_SIZE -d $O/pmcw -o b -- python3 bench.py --no-cpu-baseline --steps 3 > $O/bench_pmcw.json 2> $O/bench_pmcw.err; echo "pmcw rc=$?"
 timeout -k 10 240 rocprofv3 --output-format csv --pmc FETCH_SIZE -d $O/pmcf -o b -- python3 bench.py --no-cpu-baseline --steps 3 > $O/bench_pmcf.json 2> $O/bench_pmcf.err; echo "pmcf rc=$?"
 python3 tools/summarize_rocprof.py pmc $O/pmcw $O/bench_pmc_w.json 0
