@@ -309,6 +309,18 @@ __device__ __forceinline__ float4 lds_atom(const float4* p) {
 // MATH: 0 = product arithmetic with the hardware sqrt, 1 = with the correctly rounded sqrt (cfg.exact_sqrt).
 // Builds made with -DPS_EXPERIMENTS (tools/ only, never the product library) add two timing experiments:
 //       2 = stores without any arithmetic (WRONG values);  3 = the first correctly rounded routine (same values as 1).
+// The same arithmetic with the subtractions and squares as two packed operations on the (x, y) and (z, w) register pairs
+// (v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue slot; the operands are the even-aligned halves of the
+// float4 a ds_read_b128 delivers).  Values are bit-identical: every operation rounds exactly as its scalar twin, and
+// the sum keeps the reference's order (sx + sy) + sz.
+template <bool EXACT>
+__device__ __forceinline__ float dist_pp_pk(float4 p, float4 q) {
+    const f32x2 dxy = f32x2{p.x, p.y} - f32x2{q.x, q.y}, dzw = f32x2{p.z, p.w} - f32x2{q.z, q.w};
+    const f32x2 sxy = dxy * dxy, szw = dzw * dzw;
+    const float x = (sxy.x + sxy.y) + szw.x;
+    return EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
+}
+
 template <int MATH>
 __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
 #ifdef PS_EXPERIMENTS
@@ -320,7 +332,44 @@ __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
 #else
     static_assert(MATH == 0 || MATH == 1, "experiment modes are compiled only with -DPS_EXPERIMENTS");
 #endif
-    return MATH == 0 ? dist_pp<false>(p, q) : dist_pp<true>(p, q);
+    return MATH == 0 ? dist_pp_pk<false>(p, q) : dist_pp_pk<true>(p, q);
+}
+
+// The pattern kernel's per-lane slot decode is the same for every workgroup, so it is a compile-time table
+// (one 16-byte load per lane instead of ~90 VALU instructions of divisions by 225 and 15):
+//   offj: byte k = column atom (jo * RS + c) of element 4 t + k inside a 4-residue group   (float4 slot index in LDS)
+//   ai:   byte k = row atom a of that element
+//   mask: the lane's 16-byte mask window inside a 16-residue group starts at byte 16 t = (jo, a, c); bits 0-3 jo,
+//         4-7 jo1, 8-11 a, 12-15 a1, 16-19 c, where (jo1, a1) is the (column residue, row atom) the window runs on into
+struct pat_lane_t { uint32_t offj, ai, mask, pad; };
+struct pat_table_t { pat_lane_t lane[256]; };
+constexpr pat_table_t make_pat_table() {
+    pat_table_t t{};
+    for (unsigned tid = 0; tid < 256; ++tid) {
+        pat_lane_t l{0, 0, 0, 0};
+        for (unsigned k = 0; k < 4; ++k) {
+            const unsigned e = (4 * tid + k) % 900;   // lanes >= 225 are idle; keep their entries in range
+            const unsigned jo = e / AA15, r = e % AA15, a = r / A15, c = r % A15;
+            l.offj |= (jo * 16 + c) << (8 * k);
+            l.ai |= a << (8 * k);
+        }
+        const unsigned e0 = (16 * tid) % 3600;
+        const unsigned jo = e0 / AA15, r = e0 % AA15, a = r / A15, c = r % A15;
+        const bool wa = (a == A15 - 1);
+        const unsigned a1 = wa ? 0u : a + 1u, jo1 = wa ? jo + 1u : jo;   // jo1 <= 15: the last lane's window ends with its group
+        l.mask = jo | ((jo1 & 15u) << 4) | (a << 8) | (a1 << 12) | (c << 16);
+        t.lane[tid] = l;
+    }
+    return t;
+}
+__device__ const pat_table_t K1_PAT = make_pat_table();
+
+struct __attribute__((packed, aligned(4))) xyz12 { float x, y, z; };   // one atom of the (.., A, 3) input: 12 bytes, 4-byte aligned
+
+// the 15 mask bits of staged residue r from the pattern kernel's bit stream (bit 15 r + c = atom c of residue r)
+__device__ __forceinline__ uint32_t res_bits(const uint32_t* sbits, unsigned r) {
+    const unsigned o = r * 15u;
+    return __funnelshift_r(sbits[o >> 5], sbits[(o >> 5) + 1], o & 31u) & 0x7FFFu;
 }
 
 template <int JT, bool NT, int MATH, bool UNROLL>
@@ -333,8 +382,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sxj = reinterpret_cast<float4*>(smem);
     float4* sxi = sxj + JT * RS;
-    uint32_t* smj = reinterpret_cast<uint32_t*>(sxi + IR * RS);
-    uint32_t* smi = smj + (JT + 4);
+    constexpr int NPU = ((JT + 1) * A15 + 255) / 256;                // staging passes that cover JT column residues + one row residue
+    uint32_t* sbits = reinterpret_cast<uint32_t*>(sxi + IR * RS);    // mask bit stream: 8 words per 256 staged atoms, + 1
 
     const int tid = threadIdx.x;
     // 1-D grid.  Workgroups are dealt round-robin to the 8 XCDs (ids equal mod 8 share an XCD and its L2), so with
@@ -351,36 +400,52 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
     const int in = min(IR, row_end - i0);
 
+    // Staging, one atom per lane and pass: a 12-byte global load and one 16-byte LDS write.  The staged residues (jn
+    // column residues, then the `in` row residues) form one atom stream u = 0 .. 15 (jn + in) - 1; the loads of its first
+    // NPU passes -- all of it when the workgroup has one row -- are issued before anything waits on them, so a
+    // workgroup pays one memory latency.  Atom u's mask bit goes through a wave ballot into a bit stream (bit u), read
+    // back 15 bits at a time by res_bits().  (Round 3: the float-per-lane loop this replaces spent ~17 VALU
+    // instructions, four of them quarter-rate multiplies, per staged FLOAT -- a quarter of the kernel's vector time.)
+    const pat_lane_t lane_pat = K1_PAT.lane[tid];   // this lane's fixed slot decode (a constant table; used after the barrier)
     {
-        const float* gj = xyz + ((size_t)b * N + j0) * (A15 * 3);
-        float* lj = reinterpret_cast<float*>(sxj);
-        for (int f = tid; f < jn * (A15 * 3); f += 256) {
-            int atom = f / 3, comp = f - atom * 3;
-            int res = atom / A15, c = atom - res * A15;
-            lj[(res * RS + c) * 4 + comp] = gj[f];
-        }
-        const float* gi = xyz + ((size_t)b * N + i0) * (A15 * 3);
-        float* li = reinterpret_cast<float*>(sxi);
-        for (int f = tid; f < in * (A15 * 3); f += 256) {
-            int atom = f / 3, comp = f - atom * 3;
-            int res = atom / A15, c = atom - res * A15;
-            li[(res * RS + c) * 4 + comp] = gi[f];
-        }
-        for (int r = tid; r < JT + 4 + IR; r += 256) {
-            bool is_j = r < JT + 4;
-            int rl = is_j ? r : r - (JT + 4);
-            bool valid = is_j ? (rl < jn) : (rl < in);
-            uint32_t bits = 0;
-            if (valid) {
-                if (amask) {
-                    const uint8_t* m = amask + ((size_t)b * N + (is_j ? j0 : i0) + rl) * A15;
+        const int lane = tid & 63, wbase = tid - lane;
+        const unsigned nj = (unsigned)jn * A15, total = nj + (unsigned)in * A15;
+        const float* gb = xyz + (size_t)b * N * (A15 * 3);                       // this structure
+        const uint8_t* mb = amask ? amask + (size_t)b * N * A15 : nullptr;
+        const unsigned res_j = (unsigned)j0, res_i = (unsigned)i0 - (unsigned)jn;   // atom u lives in residue res_x + u / 15 ...
+        const unsigned slot_i = 16u * (unsigned)(JT - jn);                       // ... and in LDS slot u + u / 15 (+ slot_i)
+        auto src_atom = [&](unsigned u) { return (u < nj ? res_j : res_i) * A15 + u; };   // atom index in the structure
+        auto dst_slot = [&](unsigned u) { return u + (__umul24(u, 34953u) >> 19) + (u < nj ? 0u : slot_i); };
+        xyz12 pa[NPU];
+        uint32_t ma[NPU];
 #pragma unroll
-                    for (int c = 0; c < A15; ++c) bits |= (m[c] != 0 ? 1u : 0u) << c;
-                } else {
-                    bits = 0x7FFFu;
-                }
+        for (int p = 0; p < NPU; ++p) {
+            const unsigned u = (unsigned)(p * 256 + tid);
+            ma[p] = 0;
+            if (u < total) {
+                const unsigned at = src_atom(u);
+                pa[p] = *reinterpret_cast<const xyz12*>(gb + 3u * at);
+                ma[p] = mb ? (uint32_t)mb[at] : 1u;
             }
-            (is_j ? smj : smi)[rl] = bits;
+        }
+#pragma unroll
+        for (int p = 0; p < NPU; ++p) {
+            const unsigned u = (unsigned)(p * 256 + tid);
+            if (u < total) sxj[dst_slot(u)] = make_float4(pa[p].x, pa[p].y, pa[p].z, 0.f);
+            const unsigned long long bal = __ballot(ma[p] != 0);
+            if (lane < 2) sbits[((p * 256 + wbase) >> 5) + lane] = lane ? (uint32_t)(bal >> 32) : (uint32_t)bal;
+        }
+        for (unsigned base = NPU * 256; base < total; base += 256) {   // more than one row per workgroup (uniform trip count)
+            const unsigned u = base + (unsigned)tid;
+            uint32_t m = 0;
+            if (u < total) {
+                const unsigned at = src_atom(u);
+                const xyz12 q = *reinterpret_cast<const xyz12*>(gb + 3u * at);
+                sxj[dst_slot(u)] = make_float4(q.x, q.y, q.z, 0.f);
+                m = mb ? (uint32_t)mb[at] : 1u;
+            }
+            const unsigned long long bal = __ballot(m != 0);
+            if (lane < 2) sbits[((base + wbase) >> 5) + lane] = lane ? (uint32_t)(bal >> 32) : (uint32_t)bal;
         }
     }
     __syncthreads();
@@ -389,14 +454,11 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     const size_t row0 = ((size_t)b * out_rows + (size_t)(i0 - out_row_origin)) * N + j0;  // pair index of (i0, j0)
 
     if (dist) {
-        unsigned offj[4], ai[4];
+        unsigned offj[4], ai[4];   // element k of this lane's slot: column atom (jo * RS + c) of the group, row atom a
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned e = 4u * tid + k;  // element inside a 4-residue group
-            const unsigned jo = e / AA15, r = e - jo * AA15;
-            const unsigned a = r / A15, c = r - a * A15;
-            offj[k] = jo * RS + c;
-            ai[k] = a;
+            offj[k] = (lane_pat.offj >> (8 * k)) & 0xFFu;
+            ai[k] = (lane_pat.ai >> (8 * k)) & 0xFFu;
         }
         const int ngroups = jn >> 2;
         for (int il = 0; il < in; ++il) {
@@ -435,22 +497,20 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     }
 
     if (dmask) {
-        const unsigned e0 = 16u * tid;  // byte inside a 16-residue group
-        const unsigned jo = e0 / AA15, r = e0 - jo * AA15;
-        const unsigned a = r / A15, c = r - a * A15;
-        const bool wa = (a == A15 - 1);
-        const unsigned a1 = wa ? 0u : a + 1u;
-        const unsigned jo1 = wa ? jo + 1u : jo;
+        // this lane's 16-byte window of a 16-residue group starts at column atom (jo, c) of row atom a and may run on
+        // into row atom a1 of column residue jo1 (pat_table below)
+        const unsigned jo = lane_pat.mask & 15u, jo1 = (lane_pat.mask >> 4) & 15u, a = (lane_pat.mask >> 8) & 15u;
+        const unsigned a1 = (lane_pat.mask >> 12) & 15u, c = (lane_pat.mask >> 16) & 15u;
         constexpr int NG = JT / 16;
         uint32_t mj0[NG], mj1[NG];
+        const int ngroups = jn >> 4;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            mj0[g] = smj[g * 16 + jo];
-            mj1[g] = smj[g * 16 + jo1] << 15;
+            mj0[g] = g < ngroups ? res_bits(sbits, g * 16 + jo) : 0u;
+            mj1[g] = g < ngroups ? res_bits(sbits, g * 16 + jo1) << 15 : 0u;
         }
-        const int ngroups = jn >> 4;
         for (int il = 0; il < in; ++il) {
-            const uint32_t mib = smi[il];
+            const uint32_t mib = res_bits(sbits, (unsigned)(jn + il));
             const uint32_t k0 = ((mib >> a) & 1u) ? 0xFFFFFFFFu : 0u;
             const uint32_t k1 = ((mib >> a1) & 1u) ? 0xFFFFFFFFu : 0u;
             uint8_t* o = dmask + (row0 + (size_t)il * N) * AA15 + 16u * tid;
@@ -1387,6 +1447,8 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
           amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR)
 #define PS_K1_LAUNCH(NT_, DA_, MA_) (ex ? PS_K1_LAUNCH1(NT_, DA_, MA_, true) : PS_K1_LAUNCH1(NT_, DA_, MA_, false))
     if (da && ma && g.variant == 0) {
+        // LDS: padded float4 images of the JT column and IR row residues, then the two mask bit streams (at most
+        // (JT * 15 / 256 + 1) * 8 + (IR * 15 / 256 + 1) * 8 + 1 words, which JT + 4 + IR words always cover for JT >= 32)
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
                                (size_t)g.lds_pad_kb * 1024;
         const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
@@ -1588,7 +1650,7 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4 || g.flat == 3) return false;
     if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < 0 || g.lds_pad_kb > 120) return false;
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
-    if (g.jt != 0 && g.jt != 32 && g.jt != 64 && g.jt != 128) return false;
+    if (g.jt != 0 && g.jt != 16 && g.jt != 32 && g.jt != 64 && g.jt != 128) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
     if (g.rowphase < 0 || g.rowphase > 2) return false;
 #ifdef PS_EXPERIMENTS
@@ -1683,6 +1745,9 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         if (jt == 128)
             return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,
                                    out_row_origin, go);
+        if (jt == 16)
+            return launch_a15<16>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
+                                  go);
         if (jt == 32)
             return launch_a15<32>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin,
                                   go);
