@@ -65,11 +65,15 @@ __device__ __forceinline__ void store16(void* p, uint4 v) {
 // never more -- tools/microbench/sqrt_check.hip; the reference's own torch.norm is 1 ulp away from this formula on
 // ~11 % of entries).  EXACT = true: correctly rounded (sqrt_rn_mk), 22 more VALU instructions per 16-byte slot, which
 // on the devices that can store at 7 TB/s costs 10-16 % of K1's speed (profiles/r01_k1_ab_sqrt_mk.log).
+// The subtractions and squares of x and y are one packed operation each (v_pk_add_f32 / v_pk_mul_f32 on the even-aligned
+// (x, y) half of the float4 a ds_read_b128 delivers: two lanes of work per issue slot).  Every operation rounds exactly as
+// its scalar twin and the sum keeps the reference's order (sx + sy) + sz, so the values are those of the scalar formula.
 template <bool EXACT>
 __device__ __forceinline__ float dist_pp(float4 p, float4 q) {
-    float dx = p.x - q.x, dy = p.y - q.y, dz = p.z - q.z;
-    float sx = dx * dx, sy = dy * dy, sz = dz * dz;
-    const float x = (sx + sy) + sz;
+    const f32x2 dxy = f32x2{p.x, p.y} - f32x2{q.x, q.y};
+    const f32x2 sxy = dxy * dxy;
+    const float dz = p.z - q.z, sz = dz * dz;
+    const float x = (sxy.x + sxy.y) + sz;
     return EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
 }
 
@@ -309,18 +313,6 @@ __device__ __forceinline__ float4 lds_atom(const float4* p) {
 // MATH: 0 = product arithmetic with the hardware sqrt, 1 = with the correctly rounded sqrt (cfg.exact_sqrt).
 // Builds made with -DPS_EXPERIMENTS (tools/ only, never the product library) add two timing experiments:
 //       2 = stores without any arithmetic (WRONG values);  3 = the first correctly rounded routine (same values as 1).
-// The same arithmetic with the subtractions and squares as two packed operations on the (x, y) and (z, w) register pairs
-// (v_pk_add_f32 / v_pk_mul_f32: two lanes of work per issue slot; the operands are the even-aligned halves of the
-// float4 a ds_read_b128 delivers).  Values are bit-identical: every operation rounds exactly as its scalar twin, and
-// the sum keeps the reference's order (sx + sy) + sz.
-template <bool EXACT>
-__device__ __forceinline__ float dist_pp_pk(float4 p, float4 q) {
-    const f32x2 dxy = f32x2{p.x, p.y} - f32x2{q.x, q.y}, dzw = f32x2{p.z, p.w} - f32x2{q.z, q.w};
-    const f32x2 sxy = dxy * dxy, szw = dzw * dzw;
-    const float x = (sxy.x + sxy.y) + szw.x;
-    return EXACT ? sqrt_rn_mk(x) : __builtin_amdgcn_sqrtf(x);
-}
-
 template <int MATH>
 __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
 #ifdef PS_EXPERIMENTS
@@ -332,7 +324,7 @@ __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
 #else
     static_assert(MATH == 0 || MATH == 1, "experiment modes are compiled only with -DPS_EXPERIMENTS");
 #endif
-    return MATH == 0 ? dist_pp_pk<false>(p, q) : dist_pp_pk<true>(p, q);
+    return MATH == 0 ? dist_pp<false>(p, q) : dist_pp<true>(p, q);
 }
 
 // The pattern kernel's per-lane slot decode is the same for every workgroup, so it is a compile-time table
@@ -566,6 +558,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
     __shared__ uint32_t smj[FL], smi[FR], smc[FL];
 
     const int tid = threadIdx.x;
+    const pat_lane_t lane_pat = K1_PAT.lane[tid];   // this lane's fixed slot decode (constant table)
     unsigned w = blockIdx.x;
     if (xcd_remap) {  // XCD x (= w % 8) sweeps a contiguous share of the chunks; see the pattern kernel
         const unsigned n = gridDim.x, x = w & 7u;
@@ -669,14 +662,12 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
         if (tid >= AA15) continue;  // idle in the sweep; rejoins at the next chunk's barrier
 
         if (dist) {
-            unsigned offj[4], ai[4], jo[4];
+            unsigned offj[4], ai[4], jo[4];   // element k of this lane's slot (the pattern kernel's table, K1_PAT)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned e = 4u * tid + k;  // element inside a 4-pair group
-                jo[k] = e / AA15;
-                const unsigned r = e - jo[k] * AA15;
-                ai[k] = r / A15;
-                offj[k] = jo[k] * RS + (r - ai[k] * A15);
+                offj[k] = (lane_pat.offj >> (8 * k)) & 0xFFu;   // jo * RS + c
+                ai[k] = (lane_pat.ai >> (8 * k)) & 0xFFu;
+                jo[k] = offj[k] >> 4;
             }
             float* o = dist + (size_t)P0 * AA15 + 4u * tid;
             int rl = 0;                // row of pair 4g
