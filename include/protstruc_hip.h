@@ -66,10 +66,10 @@ typedef struct ps_k1_config {
                              flat kernel of rounds 1-2, removed: the row-phase kernel is faster at every atom count) */
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1); row-phase kernel: rows per lane
                              when > 1 (default: 8 / 16 / 32 by atom count) */
-    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 8) */
+    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 24) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
-    int jt;               /* pattern kernel: column residues per tile, 32 / 64 / 128, 0 = auto (128 from N = 256, else 64) */
+    int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32) */
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
@@ -137,7 +137,7 @@ typedef struct ps_k1_plan {
     int n_launches;             /* 0 (empty input) or 1 (every kernel writes both planes in one launch) */
     char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" |
                                    "element" (other atom counts); "empty"; a second launch would be appended with " + " */
-    char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<128>" */
+    char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<32>" */
     unsigned n_workgroups;      /* grid of the first launch */
     unsigned lds_bytes;         /* static + dynamic LDS per workgroup of the first launch */
     int threads_per_workgroup;

@@ -237,7 +237,7 @@ def set_tuning(key, value, device=None):
     if key not in _K1_KEYS:
         raise HipLibraryError(f"unknown tuning key {key!r} (known: {', '.join(sorted(_K1_KEYS))})")
     field, lo, hi = _K1_KEYS[key]
-    if not lo <= value <= hi or (key == "k1_jt" and value not in (0, 32, 64, 128)) \
+    if not lo <= value <= hi or (key == "k1_jt" and value not in (0, 16, 32, 64, 128)) \
             or (key == "k1_flat_fl_log2" and value in (1, 2, 3)) or (key == "k1_flat" and value == 3):
         raise HipLibraryError(f"tuning value {key}={value} outside its range")
     if key == "k1_experiment" and value and not load().ps_has_experiments():

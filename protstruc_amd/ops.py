@@ -156,14 +156,18 @@ _K1_LAUNCH = _k1_launch_entry
 # per CU: on 8 + 8 buffers of two boxes (profiles/r03_k1_ab_pattern_small_tiles_residency_caps*.log) "jt32 + 18 KB" is
 # within +-3 % of the default on fast buffers and 2-4 % ahead on slow ones, "jt32 + 24 KB" is 5-8 % ahead on slow and
 # medium buffers (6.3-6.6 TB/s, the best seen there) and 5-7 % behind on fast ones -- which is what a tuner is for.
+# Late round 3 (lean staging, packed arithmetic: small tiles had been VALU-bound): the default became the 32-residue tile at
+# 4 workgroups per CU (24 KB), and the candidates are its neighbours -- 5 and 6 per CU (20 / 16 KB: +1-2 % on some fast
+# buffers), 3 per CU (36 KB: +1-4 % on slow and medium buffers, -4 % on fast ones), the 16-residue tile, and the two
+# earlier defaults (profiles/r03_k1_ab_lean_*.log).
 _K1_CANDIDATE_PATTERN = (
-    {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 0},
-    {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 64},
-    {"rows_per_block": 1, "lds_pad_kb": 18, "jt": 32},
-    {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 32},
-    {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 64},
-    {"rows_per_block": 1, "lds_pad_kb": 0, "jt": 0},
-    {"rows_per_block": 2, "lds_pad_kb": 0, "jt": 0},
+    {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 0},      # the default: 32-residue tiles, 4 workgroups per CU
+    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 32},
+    {"rows_per_block": 1, "lds_pad_kb": 16, "jt": 32},
+    {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 32},
+    {"rows_per_block": 1, "lds_pad_kb": 0, "jt": 16},
+    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 64},
+    {"rows_per_block": 1, "lds_pad_kb": 8, "jt": 128},
 )
 # flat kernel (any other N >= 16): chunks per workgroup, KB of idle LDS
 # (round 3: 32-pair chunks -- 36 KB per short-lived workgroup, 4 workgroups per CU -- run 6.1-6.3 TB/s on every buffer:

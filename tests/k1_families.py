@@ -12,7 +12,8 @@ FAMILY_SHAPES = [
     # row-phase kernel, which is the default there)
     (2, 64, 15, None, False, {}, "pattern"),
     (2, 256, 15, (64, 128), False, {}, "pattern"),
-    (2, 96, 15, None, False, {"k1_jt": 32, "k1_lds_pad_kb": 24}, "pattern"),
+    (2, 96, 15, None, False, {"k1_jt": 128, "k1_lds_pad_kb": 8}, "pattern"),
+    (2, 96, 15, None, False, {"k1_jt": 16, "k1_lds_pad_kb": 0}, "pattern"),
     (3, 50, 15, None, False, {}, "flat"),
     (2, 37, 15, (5, 30), True, {}, "flat"),
     (2, 64, 15, None, False, {"k1_flat": 2, "k1_flat_fl_log2": 5}, "flat"),

@@ -57,7 +57,7 @@ def test_k1_fast_kernels_differential_fuzz():
             _lib.set_tuning("k1_rowphase", int(rng.choice([0, 0, 1, 2])) if A not in (1, 2) else 0)
             _lib.set_tuning("k1_flat_cpw", int(rng.choice([1, 2, 3, 7])))
             _lib.set_tuning("k1_rows_per_block", int(rng.choice([1, 2, 4, 5])))
-            _lib.set_tuning("k1_jt", int(rng.choice([0, 32, 64, 128])))
+            _lib.set_tuning("k1_jt", int(rng.choice([0, 16, 32, 64, 128])))
             r0 = int(rng.integers(0, N))
             r1 = int(rng.integers(r0 + 1, N + 1))
             if trial % 3 == 0:

@@ -40,9 +40,9 @@ def test_plan_headline_and_config_shapes():
     """The BASELINE shapes: headline / config 2 / config 4 (full and one of 8 row shards) take the pattern kernel."""
     for B, N, rows in ((64, 512, None), (64, 256, None), (32, 2048, None), (32, 2048, (256, 512))):
         p = _plan(B, N, 15, rows, False, {})
-        assert p["family"] == "pattern" and p["kernel"] == "k1_pairdist_a15_pat<128>"
+        assert p["family"] == "pattern" and p["kernel"] == "k1_pairdist_a15_pat<32>"
         n_rows = (rows[1] - rows[0]) if rows else N
-        assert p["n_workgroups"] == B * n_rows * (N // 128)
+        assert p["n_workgroups"] == B * n_rows * (N // 32)
     assert _lib.k1_plan(64, 500, 15, device=0)["family"] == "flat"
     assert _lib.k1_plan(8, 512, 1, device=0)["family"] == "rowphase"          # a CA trace
     assert _lib.k1_plan(0, 512, 15, device=0)["family"] == "empty"

@@ -1,7 +1,8 @@
 #!/usr/bin/python3
 """Which K1 launch configuration is fastest on WHICH output buffer?  Allocates several output-buffer pairs of the
 headline shape in one process (they land in physical memory of different "speed classes") and
-times a list of configurations on each, interleaved.  Informs the autotuner's candidate list; results are identical
+times a list of configurations on each, interleaved (unnamed knobs: the 128-residue tile + 8 KB that was the default
+until late round 3).  Informs the autotuner's candidate list; results are identical
 for every configuration.  Usage: python3 tools/k1_ab_buffers.py [n_buffers]"""
 import os
 import sys
@@ -59,7 +60,7 @@ cfgs = {
     "rowphase r8": dict(k1_rowphase=1, k1_rows_per_block=8), "rowphase r12": dict(k1_rowphase=1, k1_rows_per_block=12),
     "rowphase r16": dict(k1_rowphase=1, k1_rows_per_block=16), "rowphase r32": dict(k1_rowphase=1, k1_rows_per_block=32),
 }
-DEFAULTS = dict(k1_rows_per_block=1, k1_jt=0, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1,
+DEFAULTS = dict(k1_rows_per_block=1, k1_jt=128, k1_lds_pad_kb=8, k1_flat=1, k1_flat_fl_log2=0, k1_flat_lds_pad_kb=0, k1_flat_cpw=1,
                 k1_rowphase=0, k1_xcd_remap=1)
 if len(sys.argv) > 2:      # a comma-separated subset of configuration names
     cfgs = {k: v for k, v in cfgs.items() if any(k.startswith(p) for p in sys.argv[2].split(","))}

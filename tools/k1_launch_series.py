@@ -19,8 +19,9 @@ g = torch.Generator().manual_seed(0)
 xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
 cfgs = {
-    "default (jt128 +8KB)": dict(),
-    "jt128 +0KB": dict(k1_lds_pad_kb=0),
+    "default (jt32 +24KB)": dict(k1_jt=0, k1_lds_pad_kb=24),
+    "jt128 +8KB": dict(k1_jt=128),
+    "jt128 +0KB": dict(k1_jt=128, k1_lds_pad_kb=0),
     "jt64 +8KB": dict(k1_jt=64),
     "jt32 +0KB": dict(k1_jt=32, k1_lds_pad_kb=0),
     "jt32 +18KB": dict(k1_jt=32, k1_lds_pad_kb=18),

@@ -19,7 +19,7 @@ xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
         for _ in range(nbuf)]
-cfgs = {"default": dict(k1_jt=0, k1_lds_pad_kb=8), "jt32+24KB": dict(k1_jt=32, k1_lds_pad_kb=24)}
+cfgs = {"jt128+8KB": dict(k1_jt=128, k1_lds_pad_kb=8), "jt32+24KB": dict(k1_jt=32, k1_lds_pad_kb=24)}
 
 
 def timed(fn, reps=10):
