@@ -66,7 +66,7 @@ typedef struct ps_k1_config {
                              flat kernel of rounds 1-2, removed: the row-phase kernel is faster at every atom count) */
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1); row-phase kernel: rows per lane
                              when > 1 (default: 8 / 16 / 32 by atom count) */
-    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 24) */
+    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 20) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
     int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32) */

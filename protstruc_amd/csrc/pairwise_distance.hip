@@ -1667,7 +1667,7 @@ extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
     cfg->rows_per_block = 1;
     // 8 KB of idle LDS per workgroup of the pattern kernel (resident workgroups per CU 4 -> 3): with 1 row per workgroup
     // the fastest configuration on every output buffer measured, fast or slow (profiles/r02_k1_ab_buffers.log)
-    cfg->lds_pad_kb = 24;
+    cfg->lds_pad_kb = 20;
     cfg->flat_cpw = 1;
     cfg->xcd_remap = 1;
 }
@@ -1737,9 +1737,9 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         // N < 16 (peptides): a row run is at most 13.5 KB, so the slot-decode kernel takes up to 16 rows per workgroup
         if (N < 16 && g.rows_per_block == 1) g.rows_per_block = rows < 16 ? rows : 16;
         if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
-        // default tile: 32 column residues (36 KB + 9 KB of output per workgroup) at the default 24 KB of idle LDS = 4
-        // workgroups per CU: the best or within 2 % of it on every output buffer measured with the round-3 kernel (7.2-7.3
-        // TB/s fast class, 6.2-6.5 slow; 128-residue tiles + 8 KB, the default until then: 7.1 / 5.9)
+        // default tile: 32 column residues (36 KB + 9 KB of output per workgroup) at the default 20 KB of idle LDS = 5
+        // workgroups per CU: with the round-3 kernel the best or within 2 % of it on the output buffers of ten boxes (7.0-7.3
+        // TB/s fast class, 6.1-6.4 slow; 128-residue tiles + 8 KB, the default until then: 6.8-7.1 / 5.9)
         const int jt = g.jt ? g.jt : 32;
         if (jt == 128)
             return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,

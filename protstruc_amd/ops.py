@@ -157,12 +157,12 @@ _K1_LAUNCH = _k1_launch_entry
 # within +-3 % of the default on fast buffers and 2-4 % ahead on slow ones, "jt32 + 24 KB" is 5-8 % ahead on slow and
 # medium buffers (6.3-6.6 TB/s, the best seen there) and 5-7 % behind on fast ones -- which is what a tuner is for.
 # Late round 3 (lean staging, packed arithmetic: small tiles had been VALU-bound): the default became the 32-residue tile at
-# 4 workgroups per CU (24 KB), and the candidates are its neighbours -- 5 and 6 per CU (20 / 16 KB: +1-2 % on some fast
-# buffers), 3 per CU (36 KB: +1-4 % on slow and medium buffers, -4 % on fast ones), the 16-residue tile, and the two
-# earlier defaults (profiles/r03_k1_ab_lean_*.log).
+# 5 workgroups per CU (20 KB), and the candidates are its neighbours -- 4 per CU (24 KB: +1 % on slow buffers and on some
+# fast ones, -3 % on others), 6 per CU (16 KB), 3 per CU (36 KB: +1-4 % on slow and medium buffers, -4 % on fast ones), the
+# 16-residue tile, and the two earlier defaults (profiles/r03_k1_ab_lean_*.log).
 _K1_CANDIDATE_PATTERN = (
-    {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 0},      # the default: 32-residue tiles, 4 workgroups per CU
-    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 32},
+    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 0},      # the default: 32-residue tiles, 5 workgroups per CU
+    {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 16, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 0, "jt": 16},

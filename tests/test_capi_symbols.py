@@ -53,7 +53,7 @@ def test_python_binding_matches_header(lib_path):
     lib.ps_k1_config_default(ctypes.byref(cfg))
     assert cfg.struct_size == ctypes.sizeof(_lib.K1Config)
     assert (cfg.flat, cfg.rows_per_block, cfg.flat_cpw, cfg.xcd_remap, cfg.exact_sqrt, cfg.experiment) == (1, 1, 1, 1, 0, 0)
-    assert cfg.lds_pad_kb == 24
+    assert cfg.lds_pad_kb == 20
 
 
 def test_tuning_is_a_per_device_host_table(lib_path):

@@ -19,7 +19,7 @@ g = torch.Generator().manual_seed(0)
 xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
 cfgs = {
-    "default (jt32 +24KB)": dict(k1_jt=0, k1_lds_pad_kb=24),
+    "default (jt32 +20KB)": dict(k1_jt=0, k1_lds_pad_kb=20),
     "jt128 +8KB": dict(k1_jt=128),
     "jt128 +0KB": dict(k1_jt=128, k1_lds_pad_kb=0),
     "jt64 +8KB": dict(k1_jt=64),
