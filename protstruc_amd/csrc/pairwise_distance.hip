@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
                                                            float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                            int N, int row_begin, int row_end, int out_rows,
                                                            int out_row_origin, int IR, int n_tiles, int n_ichunks,
-                                                           int xcd_remap, int pace) {
+                                                           int xcd_remap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* sxj = reinterpret_cast<float4*>(smem);
     float4* sxi = sxj + JT * RS;
@@ -477,9 +477,6 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
                     u.w = __float_as_uint(dist_pp_m<MATH>(pi[3], q3));
                 }
                 store16<NT>(o + (size_t)g * (4 * AA15), u);
-#ifdef PS_EXPERIMENTS
-                for (int q = 0; q < pace; ++q) __builtin_amdgcn_s_sleep(1);   // pacing experiment, 64 clocks each (NOTES.md: no gain)
-#endif
             };
             if (UNROLL && ngroups == JT / 4) {  // full tile: straight-line code, stores issued back to back
 #pragma unroll
@@ -1451,10 +1448,8 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
 #define PS_K1_PAT(NT_, M_, U_)                                                                                    \
     k1_go(go, "pattern", "k1_pairdist_a15_pat", JT, k1_pairdist_a15_pat<JT, NT_, M_, U_>, dim3((unsigned)n_wg),   \
           dim3(256), lds_pat, xyz, amask, dist, dmask, N, row_begin, row_end, out_rows, out_row_origin, IR,       \
-          (int)grid.x, (int)grid.y, remap, pace)
-        int pace = 0;
+          (int)grid.x, (int)grid.y, remap)
 #ifdef PS_EXPERIMENTS
-        pace = (g.experiment >> 8) & 63;
         const int math = g.experiment & 15;
         const bool unroll = (g.experiment & 16) != 0;
         if (math == 1) return PS_K1_PAT(false, 3, false);
@@ -1650,7 +1645,7 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
     if (g.rowphase < 0 || g.rowphase > 2) return false;
 #ifdef PS_EXPERIMENTS
-    if (g.experiment < 0 || (g.experiment & 15) > 2 || (g.experiment & 0xFF) > 31 || g.experiment > 0x3FFF) return false;
+    if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
 #else
     if (g.experiment != 0) return false;   // timing experiments do not exist in the product library
 #endif
