@@ -221,9 +221,10 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False
         while time.perf_counter() < t_end:
             launch(0)
             torch.cuda.current_stream(device).synchronize()
-        # Each candidate's figure is the MEDIAN over the rounds of a 3-launch mean, not its minimum: the small-tile
-        # candidates spread 3-4 % from launch to launch on fast buffers where the default spreads 1 %
-        # (profiles/r03_k1_launch_series.log), and a caller's steady state sees the mean.
+        # Each candidate's figure is its MEAN over all rounds (5 x 3 launches), not its minimum or median: the small-tile
+        # kernels spread 3-4 % from launch to launch with a tail of slow launches (profiles/r03_k1_launch_series.log;
+        # a median of 2.60 ms went with a 20-launch mean of 2.72 ms in profiles/r03_final_bench_n1.json), and a caller's
+        # throughput is the reciprocal of the mean.
         rounds = [[] for _ in candidates]
         for _ in range(5):
             for k in range(len(candidates)):
@@ -236,7 +237,7 @@ def _autotune_k1(device, args, n_pairs: int, N: int, A: int, force: bool = False
                 e1.record()
                 e1.synchronize()
                 rounds[k].append(e0.elapsed_time(e1) / 3)
-        timings = [sorted(r)[len(r) // 2] for r in rounds]
+        timings = [sum(r) / len(r) for r in rounds]
         best = 0
         for k in range(1, len(candidates)):
             if timings[k] < timings[best] * 0.99:   # prefer the earlier candidate unless the gain is clear (1 %)
