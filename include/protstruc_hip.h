@@ -64,8 +64,9 @@ typedef struct ps_k1_config {
                              where it is the fast path; 2: force the A = 15 flat pattern kernel; 4: force the fixed-A flat
                              pattern kernel (A = 14, 15, 16, 24, 32) and no row-tile / row-phase kernel.  (3 was the any-A
                              flat kernel of rounds 1-2, removed: the row-phase kernel is faster at every atom count) */
-    int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1); row-phase kernel: rows per lane
-                             when > 1 (default: 8 / 16 / 32 by atom count) */
+    int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1, which for chains shorter than 64
+                             residues means ceil(64 / N) rows); row-phase kernel: rows per lane when > 1 (default: 12 / 16 / 32
+                             by atom count); row-tile kernel: rows per workgroup when > 1 (default 6) */
     int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 20) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */

@@ -1731,6 +1731,10 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
     if (A == A15) {
         // N < 16 (peptides): a row run is at most 13.5 KB, so the slot-decode kernel takes up to 16 rows per workgroup
         if (N < 16 && g.rows_per_block == 1) g.rows_per_block = rows < 16 ? rows : 16;
+        // short chains (16 <= N < 64): a workgroup that writes one row of one tile is mostly set-up, so rows_per_block = 1
+        // (the default) means "about 64 column residues' worth of rows": N = 16: 4 rows (6.7 against 4.3 TB/s), N = 32 and 48:
+        // 2 rows (6.8 against 5.0, 6.5 against 5.9; profiles/r03_k1_short_chains_rows.log); consecutive rows are contiguous
+        else if (N < 64 && g.rows_per_block == 1) g.rows_per_block = rows < (64 + N - 1) / N ? rows : (64 + N - 1) / N;
         if ((rows + g.rows_per_block - 1) / g.rows_per_block > 65535) return (int)hipErrorInvalidValue;
         // default tile: 32 column residues (36 KB + 9 KB of output per workgroup) at the default 20 KB of idle LDS = 5
         // workgroups per CU: with the round-3 kernel the best or within 2 % of it on the output buffers of ten boxes (7.0-7.3
