@@ -332,7 +332,8 @@ __device__ __forceinline__ float dist_pp_m(float4 p, float4 q) {
 //   offj: byte k = column atom (jo * RS + c) of element 4 t + k inside a 4-residue group   (float4 slot index in LDS)
 //   ai:   byte k = row atom a of that element
 //   mask: the lane's 16-byte mask window inside a 16-residue group starts at byte 16 t = (jo, a, c); bits 0-3 jo,
-//         4-7 jo1, 8-11 a, 12-15 a1, 16-19 c, where (jo1, a1) is the (column residue, row atom) the window runs on into
+//         4-7 jo1, 8-11 a, 12-15 a1, 16-19 c, 20 wa, where (jo1, a1) is the (column residue, row atom) the window runs on
+//         into and wa says that jo1 = jo + 1 (a is the last row atom)
 struct pat_lane_t { uint32_t offj, ai, mask, pad; };
 struct pat_table_t { pat_lane_t lane[256]; };
 constexpr pat_table_t make_pat_table() {
@@ -349,7 +350,7 @@ constexpr pat_table_t make_pat_table() {
         const unsigned jo = e0 / AA15, r = e0 % AA15, a = r / A15, c = r % A15;
         const bool wa = (a == A15 - 1);
         const unsigned a1 = wa ? 0u : a + 1u, jo1 = wa ? jo + 1u : jo;   // jo1 <= 15: the last lane's window ends with its group
-        l.mask = jo | ((jo1 & 15u) << 4) | (a << 8) | (a1 << 12) | (c << 16);
+        l.mask = jo | ((jo1 & 15u) << 4) | (a << 8) | (a1 << 12) | (c << 16) | ((wa ? 1u : 0u) << 20);
         t.lane[tid] = l;
     }
     return t;
@@ -489,27 +490,34 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
     }
 
     if (dmask) {
-        // this lane's 16-byte window of a 16-residue group starts at column atom (jo, c) of row atom a and may run on
-        // into row atom a1 of column residue jo1 (pat_table below)
-        const unsigned jo = lane_pat.mask & 15u, jo1 = (lane_pat.mask >> 4) & 15u, a = (lane_pat.mask >> 8) & 15u;
-        const unsigned a1 = (lane_pat.mask >> 12) & 15u, c = (lane_pat.mask >> 16) & 15u;
+        // This lane's 16-byte window of a 16-residue group starts at byte (column residue jo, row atom a, column atom c)
+        // and runs on into row atom a1 -- of the same column residue, or, when a is the last atom ("wa"), of the next one.
+        // Column residues jo and jo + 1 are neighbours in the bit stream, so ONE 32-bit extraction per group gives
+        // both: comp = [15 bits for row atom a | 15 bits for row atom a1], to be masked per row with the two row-atom bits.
+        const unsigned jo = lane_pat.mask & 15u, a = (lane_pat.mask >> 8) & 15u, a1 = (lane_pat.mask >> 12) & 15u;
+        const unsigned c = (lane_pat.mask >> 16) & 15u;
+        const bool wa = (lane_pat.mask >> 20) & 1u;
         constexpr int NG = JT / 16;
-        uint32_t mj0[NG], mj1[NG];
+        uint32_t comp[NG];
         const int ngroups = jn >> 4;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            mj0[g] = g < ngroups ? res_bits(sbits, g * 16 + jo) : 0u;
-            mj1[g] = g < ngroups ? res_bits(sbits, g * 16 + jo1) << 15 : 0u;
+            comp[g] = 0u;
+            if (g < ngroups) {
+                const unsigned o = (unsigned)(g * 16 + (int)jo) * 15u;
+                const uint32_t w = __funnelshift_r(sbits[o >> 5], sbits[(o >> 5) + 1], o & 31u);   // residues jo, jo + 1, ...
+                const uint32_t m0 = w & 0x7FFFu;
+                comp[g] = wa ? (w & 0x3FFFFFFFu) : (m0 | (m0 << 15));
+            }
         }
         for (int il = 0; il < in; ++il) {
             const uint32_t mib = res_bits(sbits, (unsigned)(jn + il));
-            const uint32_t k0 = ((mib >> a) & 1u) ? 0xFFFFFFFFu : 0u;
-            const uint32_t k1 = ((mib >> a1) & 1u) ? 0xFFFFFFFFu : 0u;
+            const uint32_t km = (((mib >> a) & 1u) ? 0x7FFFu : 0u) | (((mib >> a1) & 1u) ? 0x3FFF8000u : 0u);
             uint8_t* o = dmask + (row0 + (size_t)il * N) * AA15 + 16u * tid;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g < ngroups) {
-                    const uint32_t win = ((mj0[g] & k0) | (mj1[g] & k1)) >> c;
+                    const uint32_t win = (comp[g] & km) >> c;
                     uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
                                          spread4((win >> 12) & 15u));
                     store16<NT>(o + (size_t)g * (16 * AA15), u);
