@@ -61,6 +61,20 @@ __device__ __forceinline__ void store16(void* p, uint4 v) {
         *reinterpret_cast<u32x4_t*>(p) = w;
 }
 
+// A run of 16-byte slots addressed the buffer way: a uniform 64-bit base in a resource descriptor (scalar registers), this
+// lane's constant 32-bit byte offset, and the slot group's byte offset as a scalar -- so stepping from group to group is
+// scalar-unit work and the vector unit spends nothing on store addresses (it spent two 64-bit adds per store before).
+// Raw buffer, stride 0, no range limit below 4 GB; 0x00020000 = 32-bit data format word of gfx90a / gfx94x / gfx950.
+struct run16 {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ __forceinline__ explicit run16(void* base)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u)) {}
+    __device__ __forceinline__ void store(unsigned lane_off, unsigned group_off, uint4 v) const {
+        u32x4_t w = {v.x, v.y, v.z, v.w};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (int)lane_off, (int)group_off, 0);
+    }
+};
+
 // EXACT = false: the hardware square root (v_sqrt_f32: exact for 84.95 % of all inputs, 1 ulp off for the rest,
 // never more -- tools/microbench/sqrt_check.hip; the reference's own torch.norm is 1 ulp away from this formula on
 // ~11 % of entries).  EXACT = true: correctly rounded (sqrt_rn_mk), 22 more VALU instructions per 16-byte slot, which
@@ -458,7 +472,9 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             float4 pi[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) pi[k] = sxi[il * RS + ai[k]];
-            float* o = dist + (row0 + (size_t)il * N) * AA15 + 4u * tid;
+            float* ob = dist + (row0 + (size_t)il * N) * AA15;   // uniform: the row's run of this tile
+            const run16 run(ob);
+            const unsigned lo = 4u * (unsigned)tid;
             const float4* xj = sxj;
             auto group = [&](int g) {
                 uint4 u;
@@ -477,7 +493,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
                     u.z = __float_as_uint(dist_pp_m<MATH>(pi[2], q2));
                     u.w = __float_as_uint(dist_pp_m<MATH>(pi[3], q3));
                 }
-                store16<NT>(o + (size_t)g * (4 * AA15), u);
+                if (NT) store16<true>(ob + (size_t)g * (4 * AA15) + lo, u);
+                else run.store(4u * lo, (unsigned)g * (16u * AA15), u);
             };
             if (UNROLL && ngroups == JT / 4) {  // full tile: straight-line code, stores issued back to back
 #pragma unroll
@@ -513,14 +530,17 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
         for (int il = 0; il < in; ++il) {
             const uint32_t mib = res_bits(sbits, (unsigned)(jn + il));
             const uint32_t km = (((mib >> a) & 1u) ? 0x7FFFu : 0u) | (((mib >> a1) & 1u) ? 0x3FFF8000u : 0u);
-            uint8_t* o = dmask + (row0 + (size_t)il * N) * AA15 + 16u * tid;
+            uint8_t* ob = dmask + (row0 + (size_t)il * N) * AA15;
+            const run16 run(ob);
+            const unsigned lo = 16u * (unsigned)tid;
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if (g < ngroups) {
                     const uint32_t win = (comp[g] & km) >> c;
                     uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
                                          spread4((win >> 12) & 15u));
-                    store16<NT>(o + (size_t)g * (16 * AA15), u);
+                    if (NT) store16<true>(ob + (size_t)g * (16 * AA15) + lo, u);
+                    else run.store(lo, (unsigned)g * (16u * AA15), u);
                 }
             }
         }
