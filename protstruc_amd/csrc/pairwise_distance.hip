@@ -73,6 +73,9 @@ struct run16 {
         u32x4_t w = {v.x, v.y, v.z, v.w};
         __builtin_amdgcn_raw_buffer_store_b128(w, rsrc, (int)lane_off, (int)group_off, 0);
     }
+    __device__ __forceinline__ void store4(unsigned lane_off, unsigned group_off, uint32_t v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)lane_off, (int)group_off, 0);
+    }
 };
 
 // EXACT = false: the hardware square root (v_sqrt_f32: exact for 84.95 % of all inputs, 1 ulp off for the rest,
@@ -698,6 +701,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                 jo[k] = offj[k] >> 4;
             }
             float* o = dist + (size_t)P0 * AA15 + 4u * tid;
+            const run16 run(dist + (size_t)P0 * AA15);   // the chunk's run: uniform base, scalar group offsets (see run16)
             int rl = 0;                // row of pair 4g
             int nb = N - j_start;      // pair position where row rl + 1 starts
             int g = 0;
@@ -724,7 +728,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                         u.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
                         u.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
                         u.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
-                        store16<false>(o + (size_t)(g + q) * (4 * AA15), u);
+                        run.store(16u * (unsigned)tid, (unsigned)(g + q) * (16u * AA15), u);
                     }
                     g += nfast;
                     continue;
@@ -746,13 +750,11 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
         }
 
         if (dmask) {
-            const unsigned e0 = 16u * tid;  // byte inside a 16-pair group
-            const unsigned jo = e0 / AA15, r = e0 - jo * AA15;
-            const unsigned a = r / A15, c = r - a * A15;
-            const bool wa = (a == A15 - 1);
-            const unsigned a1 = wa ? 0u : a + 1u;
-            const unsigned jo1 = wa ? jo + 1u : jo;
+            // this lane's 16-byte window of a 16-pair group (K1_PAT: jo, jo1, a, a1, c)
+            const unsigned jo = lane_pat.mask & 15u, jo1 = (lane_pat.mask >> 4) & 15u, a = (lane_pat.mask >> 8) & 15u;
+            const unsigned a1 = (lane_pat.mask >> 12) & 15u, c = (lane_pat.mask >> 16) & 15u;
             uint8_t* o = dmask + (size_t)P0 * AA15 + 16u * tid;
+            const run16 run(dmask + (size_t)P0 * AA15);
 #pragma unroll
             for (int g = 0; g < FL / 16; ++g) {
                 const int pg = 16 * g;
@@ -764,7 +766,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_a15_flat(const float* __re
                     if (pg >= lo && pg + 16 <= hi) {
                         uint4 u = make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
                                              spread4((win >> 12) & 15u));
-                        store16<false>(o + (size_t)g * (16 * AA15), u);
+                        run.store(16u * (unsigned)tid, (unsigned)g * (16u * AA15), u);
                     } else {
                         for (unsigned t = 0; t < 16u; ++t) {
                             const int pp = pg + (int)((c + t < (unsigned)A15) ? jo : jo1);
@@ -941,6 +943,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
                     ai[kk] = a;
                 }
                 float* o = dist + (size_t)P0 * AA + 4u * sl;
+                const run16 run(dist + (size_t)P0 * AA);   // the chunk's run: uniform base, scalar group offsets (see run16)
                 int rl = 0;                // row of pair 4g
                 int nb = N - j_start;      // pair position where row rl + 1 starts
                 int g = 0;
@@ -967,7 +970,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
                             v.y = __float_as_uint(dist_pp<EXACT>(pi[1], q1));
                             v.z = __float_as_uint(dist_pp<EXACT>(pi[2], q2));
                             v.w = __float_as_uint(dist_pp<EXACT>(pi[3], q3));
-                            store16<false>(o + (size_t)(g + q) * (4 * AA), v);
+                            run.store(16u * (unsigned)sl, (unsigned)(g + q) * (16u * AA), v);
                         }
                         g += nfast;
                         continue;
@@ -1008,6 +1011,7 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
                     sh[m] = m * A - (int)c;
                 }
                 uint8_t* o = dmask + (size_t)P0 * AA + e0;
+                const run16 run(dmask + (size_t)P0 * AA);
 #pragma unroll 1   // unrolled, the eight groups' row words stay live at once and the kernel spills
                 for (int mg = 0; mg < FLn / 16; ++mg) {
                     const int pg = 16 * mg;
@@ -1024,8 +1028,8 @@ __global__ __launch_bounds__(256, 4) void k1_pairdist_flatA(const float* __restr
                         win &= 0xFFFFu;
                         uint8_t* og = o + (size_t)mg * (16 * AA);
                         if (pg >= lo && pg + 16 <= hi) {
-                            store16<false>(og, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
-                                                          spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
+                            run.store(e0, (unsigned)mg * (16u * AA), make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u),
+                                                                                spread4((win >> 8) & 15u), spread4((win >> 12) & 15u)));
                         } else {
                             for (unsigned t = 0; t < 16u; ++t) {
                                 const int pp = pg + (int)jo + ((r + t >= (unsigned)AA) ? 1 : 0);
@@ -1135,9 +1139,10 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) q[u][kk] = sxj[jj * A + c0 + kk];   // the column atoms: registers for all rows
         }
-        float* o = dist + row0 * AA + 4u * tid;
+        float* orow = dist + row0 * AA;   // uniform: stores go the buffer way (run16), one descriptor per row
 #pragma unroll 2
         for (int il = 0; il < in; ++il) {
+            const run16 run(orow);
 #pragma unroll
             for (int u = 0; u < T::SPL; ++u) {
                 const float4 pi = sxi[il * A + ai[u]];
@@ -1146,28 +1151,29 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowtile(const float* __restri
                 v.y = __float_as_uint(dist_pp<EXACT>(pi, q[u][1]));
                 v.z = __float_as_uint(dist_pp<EXACT>(pi, q[u][2]));
                 v.w = __float_as_uint(dist_pp<EXACT>(pi, q[u][3]));
-                if (act[u]) store16<false>(o + 1024 * u, v);
+                if (act[u]) run.store(16u * (unsigned)tid, 4096u * (unsigned)u, v);
             }
-            o += row_stride;
+            orow += row_stride;
         }
     }
 
     if (dmask) {
         // 128 mask slots per row: lane t takes slot t % 128 of the rows with parity t / 128
-        const int ms = tid & (T::MS - 1), par = tid / T::MS;
+        const int ms = tid & (T::MS - 1), par = __builtin_amdgcn_readfirstlane(tid / T::MS);   // (uniform over a wave)
         const unsigned e0 = 16u * (unsigned)ms;
         const unsigned j = e0 / AA, a0 = (e0 - j * AA) / A;   // the slot covers row atoms a0 .. a0 + RPS - 1 of pair j
         if ((int)j < jn) {
             const uint32_t mj = smj[j];
-            uint8_t* o = dmask + (row0 + (size_t)par * N) * AA + e0;
+            uint8_t* orow = dmask + (row0 + (size_t)par * N) * AA;
             for (int il = par; il < in; il += 2) {
+                const run16 run(orow);
                 const uint32_t mi = smi[il] >> a0;
                 uint32_t win = 0;
 #pragma unroll
                 for (int t = 0; t < T::RPS; ++t) win |= ((mi >> t) & 1u) ? (mj << (A * t)) : 0u;
-                store16<false>(o, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
+                run.store(e0, 0u, make_uint4(spread4(win & 15u), spread4((win >> 4) & 15u), spread4((win >> 8) & 15u),
                                              spread4((win >> 12) & 15u)));
-                o += 2 * row_stride;
+                orow += 2 * row_stride;
             }
         }
     }
@@ -1208,12 +1214,15 @@ struct RowPhase {
 __host__ __device__ inline int rowphase_maxres(int A) { return (4 * 512 + 2) / (A * A) + 2; }
 
 // One slot of one row.  `xi_row`: LDS address of the row residue's atoms (uniform over the wave); od / om point at the slot
-// (float / byte offset 4 s - ph of the row run); PH = the row's phase.  The row atom of every element arrives as one
+// (float / byte offset 4 s - ph of the row run), rund / runm + `so` address the same slot the buffer way (uniform row base
+// in a descriptor + this lane's constant element offset: full slots spend no vector work on addresses); PH = the row's
+// phase.  The row atom of every element arrives as one
 // ds_read_b128 whose fourth component is that atom's mask bit (0 / 1 as an integer), so the mask costs no second lookup.
 template <int ACT, bool EXACT, int PH>
 __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, const float (&col)[7][3],
                                               const uint32_t (&aoff)[7], uint32_t cm, uint32_t valid,
-                                              float* __restrict__ od_, uint8_t* __restrict__ om_, bool wd, bool wm) {
+                                              float* __restrict__ od_, uint8_t* __restrict__ om_, bool wd, bool wm,
+                                              const run16& rund, const run16& runm, unsigned so) {
     // wd / wm: whether the distance / mask plane is produced (uniform); the pointers are only meaningful when set
     float* od = wd ? od_ : nullptr;
     uint8_t* om = wm ? om_ : nullptr;
@@ -1233,9 +1242,9 @@ __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, c
     }
     const uint32_t mw = rowbytes & spread4((cm >> WO) & 15u);
     if (vm == 15u) {
-        if (wd) store16<false>(od, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
-                                              __float_as_uint(v[3])));
-        if (wm) *reinterpret_cast<uint32_t*>(om) = mw;
+        if (wd) rund.store(4u * so, 0u, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                   __float_as_uint(v[3])));
+        if (wm) runm.store4(so, 0u, mw);
     } else {   // the slot that holds a row's start or end: this row's elements only
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1354,18 +1363,19 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
         uint8_t* rm = dmask + base;
         const bool wd = dist != nullptr, wm = dmask != nullptr;
         const char* xi_row = reinterpret_cast<const char*>(sxi + il * A);
+        const run16 rund(rd), runm(rm);
 #pragma unroll
         for (int u = 0; u < T::SPL; ++u) {
             float* od = rd + so[u];
             uint8_t* om = rm + so[u];
             if constexpr (!T::PHASED) {
-                rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm);
+                rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]);
             } else {
                 switch (ph) {   // uniform over the wave
-                    case 0: rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    case 1: rowphase_slot<ACT, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    case 2: rowphase_slot<ACT, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
-                    default: rowphase_slot<ACT, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm); break;
+                    case 0: rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
+                    case 1: rowphase_slot<ACT, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
+                    case 2: rowphase_slot<ACT, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
+                    default: rowphase_slot<ACT, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
                 }
             }
         }
