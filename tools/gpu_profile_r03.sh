@@ -1,5 +1,6 @@
 # Round-3 measurement set (run on the GPU box: bash tools/gpu_profile_r03.sh [outdir-name]):
-#   the headline bench plain, under rocprofv3 --kernel-trace --stats, and under the WRITE_SIZE / FETCH_SIZE counter passes
+#   the headline bench plain, under rocprofv3 --kernel-trace --stats (with --no-lottery, so that the LAST `steps` K1
+#   dispatches of the trace are the timed region), and under the WRITE_SIZE / FETCH_SIZE counter passes
 #   (separate runs, as the guide prescribes) -> profiles/k1_traffic.json; K3 at config 3 under the kernel trace and one SQ
 #   counter pass (VALU instructions per pair).
 set -o pipefail
@@ -7,7 +8,7 @@ O=gpurun_out/${1:-r03e}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 240 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python3 bench.py --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err; echo "trace rc=$?"
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python3 bench.py --no-cpu-baseline --no-lottery > $O/bench_traced.json 2> $O/bench_traced.err; echo "trace rc=$?"
 python3 tools/summarize_rocprof.py stats $O/trace $O/bench_kernel_stats.csv
 # the kernel the timed launches took (the tuner may have picked another tile length than the default <128>)
 K=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['roofline']['kernel'].rstrip('>'))" $O/bench_traced.json)
