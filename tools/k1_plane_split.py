@@ -19,7 +19,13 @@ xyz = torch.randn(B, N, A, 3, generator=g).cuda()
 mask = (torch.rand(B, N, A, generator=g) < 0.9).cuda()
 bufs = [(torch.empty(B, N, N, A, A, device="cuda"), torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda"))
         for _ in range(nbuf)]
-cfgs = {"jt128+8KB": dict(k1_jt=128, k1_lds_pad_kb=8), "jt32+24KB": dict(k1_jt=32, k1_lds_pad_kb=24)}
+cfgs = {"jt128+8KB": dict(k1_jt=128, k1_lds_pad_kb=8, k1_xcd_remap=1), "jt32+20KB": dict(k1_jt=32, k1_lds_pad_kb=20, k1_xcd_remap=1),
+        # without the XCD-contiguous map consecutive workgroups (= consecutive runs) go to different XCDs, like torch.fill_'s;
+        # the 32-residue tile's mask runs (7200 B) then share 128-byte lines across XCDs, the 128-residue tile's (28800 B) do not
+        "jt32+20KB noremap": dict(k1_jt=32, k1_lds_pad_kb=20, k1_xcd_remap=0),
+        "jt32+0KB noremap": dict(k1_jt=32, k1_lds_pad_kb=0, k1_xcd_remap=0),
+        "jt128+8KB noremap": dict(k1_jt=128, k1_lds_pad_kb=8, k1_xcd_remap=0),
+        "jt128+0KB noremap": dict(k1_jt=128, k1_lds_pad_kb=0, k1_xcd_remap=0)}
 
 
 def timed(fn, reps=10):
@@ -47,7 +53,7 @@ for k, (d, m) in enumerate(bufs):
         two = timed(lambda: (ops.pairwise_distance(xyz, mask, out_dist=d, want_mask=False),
                              ops.pairwise_distance(xyz, mask, out_mask=m, want_dist=False)))
         nb = d.numel()
-        print(f"buf{k} {name:10s} both {both:.3f} ms ({nb * 5 / both / 1e9:.2f} TB/s) | dist only {donly:.3f} ({nb * 4 / donly / 1e9:.2f}) | "
+        print(f"buf{k} {name:18s} both {both:.3f} ms ({nb * 5 / both / 1e9:.2f} TB/s) | dist only {donly:.3f} ({nb * 4 / donly / 1e9:.2f}) | "
               f"mask only {monly:.3f} ({nb / monly / 1e9:.2f}) | two launches {two:.3f} ({nb * 5 / two / 1e9:.2f})", flush=True)
 
 # second part (argv[2] == "grid"): the single-plane launches over tile length x idle LDS, first and last buffer only
