@@ -48,6 +48,8 @@ for A, N, *rest in shapes:       # "A:N" or "A:N:B"
     for kb in range(nbuf):
         d = torch.empty(B, N, N, A, A, device="cuda")
         m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+        if os.environ.get("K1_PRINT_PTRS"):
+            print(f"buf{kb}: dist at {d.data_ptr():#x} (mod 1 GiB {d.data_ptr() % (1 << 30):#x})  mask at {m.data_ptr():#x}", flush=True)
         for spec in specs:
             cfgs = [make_cfg(lib, spec) for lib in libs]
 
