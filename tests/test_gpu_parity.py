@@ -242,7 +242,7 @@ def test_k1_store_policy_variants_agree(SB):
         for var in (0, 1):          # pattern kernel / slot-decode kernel
             for jt in (0, 16, 32, 64, 128):
                 for nt in (0, 1):
-                    for rows in (1, 3, 8, 16):
+                    for rows in (1, 3, 8, 16, 32):
                         _lib.set_tuning("k1_variant", var)
                         _lib.set_tuning("k1_jt", jt)
                         _lib.set_tuning("k1_store_nt", nt)
