@@ -581,7 +581,7 @@ def main():
             nb = B * N_RES * N_RES * BYTES_PER_PAIR
             result["roofline"]["allocation_lottery"] = {
                 "what": "informational, measured after and outside the timed region: K1 on 4 fresh (dist, mask) allocations "
-                        "of this process, min of 2 rounds of 2 launches each; NOT the figures above",
+                        "of this process, mean of 3 interleaved rounds of 3 launches each; NOT the figures above",
                 "ms_per_candidate": lot["ms_per_candidate"],
                 "frac_of_hbm_peak_per_candidate": [nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS for ms in lot["ms_per_candidate"]],
                 "kept_pair_timed_like_the_headline": {
