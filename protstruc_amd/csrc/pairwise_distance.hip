@@ -434,14 +434,14 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             ma[p] = 0;
             if (u < total) {
                 const unsigned at = src_atom(u);
-                pa[p] = *reinterpret_cast<const xyz12*>(gb + 3u * at);
+                if (dist) pa[p] = *reinterpret_cast<const xyz12*>(gb + 3u * at);   // (a mask-only launch needs no coordinates)
                 ma[p] = mb ? (uint32_t)mb[at] : 1u;
             }
         }
 #pragma unroll
         for (int p = 0; p < NPU; ++p) {
             const unsigned u = (unsigned)(p * 256 + tid);
-            if (u < total) sxj[dst_slot(u)] = make_float4(pa[p].x, pa[p].y, pa[p].z, 0.f);
+            if (dist && u < total) sxj[dst_slot(u)] = make_float4(pa[p].x, pa[p].y, pa[p].z, 0.f);
             const unsigned long long bal = __ballot(ma[p] != 0);
             if (lane < 2) sbits[((p * 256 + wbase) >> 5) + lane] = lane ? (uint32_t)(bal >> 32) : (uint32_t)bal;
         }
@@ -450,8 +450,10 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
             uint32_t m = 0;
             if (u < total) {
                 const unsigned at = src_atom(u);
-                const xyz12 q = *reinterpret_cast<const xyz12*>(gb + 3u * at);
-                sxj[dst_slot(u)] = make_float4(q.x, q.y, q.z, 0.f);
+                if (dist) {
+                    const xyz12 q = *reinterpret_cast<const xyz12*>(gb + 3u * at);
+                    sxj[dst_slot(u)] = make_float4(q.x, q.y, q.z, 0.f);
+                }
                 m = mb ? (uint32_t)mb[at] : 1u;
             }
             const unsigned long long bal = __ballot(m != 0);
@@ -1777,7 +1779,9 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         // default tile: 32 column residues (36 KB + 9 KB of output per workgroup) at the default 20 KB of idle LDS = 5
         // workgroups per CU: with the round-3 kernel the best or within 2 % of it on the output buffers of ten boxes (7.0-7.3
         // TB/s fast class, 6.1-6.4 slow; 128-residue tiles + 8 KB, the default until then: 6.8-7.1 / 5.9)
-        const int jt = g.jt ? g.jt : 32;
+        // (a mask-only launch stages no coordinates and writes a quarter of the bytes per tile: 128-residue tiles run it at the
+        // fill rate of the plane, 6.8 TB/s, where 32-residue tiles are set-up bound at 5.4; profiles/r03_k1_plane_split_mask_only.log)
+        const int jt = g.jt ? g.jt : (dist ? 32 : 128);
         if (jt == 128)
             return launch_a15<128>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows,
                                    out_row_origin, go);
