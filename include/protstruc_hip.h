@@ -73,7 +73,7 @@ typedef struct ps_k1_config {
     int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32) */
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
-    int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = 7 (128 pairs, 144 KB per chunk) */
+    int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
     int rowphase;         /* row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
                              dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel; 1 also for A = 14, 15, 16,
                              24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead) */

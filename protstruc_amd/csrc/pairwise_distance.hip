@@ -1523,7 +1523,9 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
                     unsigned range_stride, const K1Go& go) {
     if (pbeg >= pend || n_ranges == 0) return 0;
     // chunks per range: exact for one range, an upper bound when the ranges start at different chunk phases
-    const int L2 = g.flat_fl_log2 ? g.flat_fl_log2 : 7;
+    // default chunk: 64 pairs (72 KB + 18 KB of output per workgroup): with the round-3 inner loop 4 % ahead of 128 pairs on
+    // slow and medium buffers and equal on fast ones (profiles/r03_k1_flat_chunk_sweep_final.log); 32 pairs: +8 % / -3 to -10 %
+    const int L2 = g.flat_fl_log2 ? g.flat_fl_log2 : 6;
     const unsigned FL = 1u << L2;
     const unsigned cpr = n_ranges == 1 ? ((pend + (FL - 1)) >> L2) - (pbeg >> L2) : ((pend - pbeg) >> L2) + 2;
     const unsigned long long n_chunks = (unsigned long long)n_ranges * cpr;

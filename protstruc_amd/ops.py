@@ -173,10 +173,10 @@ _K1_CANDIDATE_PATTERN = (
 # (round 3: 32-pair chunks -- 36 KB per short-lived workgroup, 4 workgroups per CU -- run 6.1-6.3 TB/s on every buffer:
 # 3-5 % ahead of the 128-pair default on slow buffers, 13 % behind on fast ones; profiles/r03_k1_ab_small_granule.log)
 _K1_CANDIDATE_FLAT = (
-    {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},      # the default: 64-pair chunks
     {"flat_cpw": 1, "flat_lds_pad_kb": 8, "flat_fl_log2": 0},
+    {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 7},
     {"flat_cpw": 2, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
-    {"flat_cpw": 4, "flat_lds_pad_kb": 0, "flat_fl_log2": 0},
     {"flat_cpw": 1, "flat_lds_pad_kb": 0, "flat_fl_log2": 5},
 )
 

@@ -20,6 +20,6 @@ def test_c99_consumer_compiles_and_links():
 def test_c99_consumer_runs_on_the_gpu():
     code, log = conftest.wait_rehearsal("c_abi_demo", 330)
     assert code == 0 and "c_abi_demo ok" in log, log[-2000:]
-    assert "K1 plan for B=2 N=21 A=15: k1_pairdist_a15_flat<128> (flat)" in log   # ps_k1_plan_f32 called from plain C
+    assert "K1 plan for B=2 N=21 A=15: k1_pairdist_a15_flat<64> (flat)" in log   # ps_k1_plan_f32 called from plain C
     assert "exact_sqrt=1" in log and "(0 one ulp off)" in log
     assert "hipGraph: 10 captured steps replayed twice, draw counter 20" in log
