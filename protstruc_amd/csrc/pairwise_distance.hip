@@ -304,11 +304,12 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15(const float* __restrict__
 // 4 column residues are 900 floats = exactly 225 float4 slots, and 16 column
 // residues are 3600 mask bytes = exactly 225 16-byte slots.  So if lane t
 // (t < 225) always takes slot t of a group, its four elements keep the SAME
-// (j offset, a, c) in every group and every row: the index decode happens once
-// per workgroup, the row atoms xi[a] it needs live in registers for a whole row,
-// and the inner loop is LDS read (immediate offsets) -> 4 distances -> one
-// 16-byte store, with no integer arithmetic besides the address bump.  31 of 256
-// lanes idle in the sweep (they still help with staging).
+// (j offset, a, c) in every group and every row: the index decode is a constant
+// of the lane (a compile-time table, K1_PAT), the row atoms xi[a] it needs live
+// in registers for a whole row, and the inner loop is LDS read (immediate
+// offsets) -> 4 distances (x / y packed) -> one 16-byte buffer-addressed store
+// with no vector integer arithmetic at all.  31 of 256 lanes idle in the sweep
+// (they still help with staging).
 //
 // LDS image: a residue is 16 float4 slots (15 atoms + 1 pad) = 256 bytes = one
 // full row of the 64 LDS banks, and atoms are fetched with ds_read_b128 (the
