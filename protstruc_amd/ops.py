@@ -112,19 +112,15 @@ def _on(device: torch.device):
 
 
 # ---- optional, per-device choice of K1's output granule per workgroup -----------------------------------------
-# How fast K1's store stream is absorbed depends on the physical memory behind the output buffers (DESIGN.md,
-# "fast and slow allocations").  With the correctly rounded square root of round 1 the best granule per workgroup
-# depended on the buffers too (2-4 residue rows per workgroup 6.25 TB/s on some, 4.9-5.4 on others), so the first
-# large call of a process timed the candidates on the caller's buffers.  With the hardware square root that spread is
-# gone: on eight buffers of one process -- two of the fast class, six of the slow one -- every configuration is within
-# 2 % of the best and ONE configuration (1 row per workgroup + 8 KB of idle LDS) is the fastest on every buffer
-# (tools/k1_ab_buffers.py, profiles/r02_k1_ab_buffers.log).  That configuration is therefore simply the default
-# (ps_k1_config_default), and nothing is timed behind the caller's back any more.  The tuner remains as an explicit
-# call -- ops.autotune_pairwise_distance(), which bench.py makes before its warm-up and reports -- or with
-# PROTSTRUC_AMD_AUTOTUNE=1 (read at import; ops.set_implicit_autotune at run time) on the first large call of each kind
-# per device; it writes that DEVICE's entry of the
-# host-side table in _lib.py (per-call argument to the library; other devices and threads are never affected) and
-# never runs during stream capture.
+# How fast K1's store stream is absorbed depends on the physical memory behind the output buffers (DESIGN.md section 4,
+# "the two classes of allocation": 6.2-7.3 TB/s for the same kernel on different allocations of one process), and so
+# does which launch configuration is the fastest.  The library default (ps_k1_config_default: 32-residue tiles, 20 KB of
+# idle LDS = 5 workgroups per CU) is the configuration that was never more than 2 % behind on the buffers of ten boxes;
+# nothing is timed behind the caller's back.  The tuner is an explicit call -- ops.autotune_pairwise_distance(), which
+# bench.py makes before its warm-up and reports -- or, with PROTSTRUC_AMD_AUTOTUNE=1 (read at import;
+# ops.set_implicit_autotune at run time), runs on the first large call of each kind per device.  It writes that DEVICE's
+# entry of the host-side table in _lib.py (a per-call argument to the library; other devices and threads are never
+# affected) and never runs during stream capture.  History of the candidates: NOTES.md.
 _K1_TUNED = {}
 _K1_TUNE_LOCK = threading.Lock()
 import os as _os
@@ -147,19 +143,12 @@ def _k1_launch_entry(*args):
 
 _K1_LAUNCH = _k1_launch_entry
 # Candidates of the explicit tuner, as ps_k1_config fields.  The default comes first: the choice moves away from it
-# only for a clear (>= 1 %) gain.  Pattern kernel (N % 16 == 0): rows per workgroup, KB of idle LDS per workgroup
-# (only lowers the number of resident workgroups per CU: fewer concurrent store streams) and column residues per
-# tile.  What the second measurement on 6 + 8 buffers showed (profiles/r02_k1_ab_buffers.log): fast buffers like the
-# 64-residue tile + 8 KB best (7.1-7.2 TB/s against 7.0), slow buffers a hard cap of 2 workgroups per CU (64-residue
-# tile + 36 KB: 6.1 TB/s on EVERY buffer, against 5.9-6.0 for everything else on a slow one and 7.0+ on a fast one).
-# Round 3 added the 32-residue tile (36 KB of contiguous output per short-lived workgroup) with 6 and with 4 workgroups
-# per CU: on 8 + 8 buffers of two boxes (profiles/r03_k1_ab_pattern_small_tiles_residency_caps*.log) "jt32 + 18 KB" is
-# within +-3 % of the default on fast buffers and 2-4 % ahead on slow ones, "jt32 + 24 KB" is 5-8 % ahead on slow and
-# medium buffers (6.3-6.6 TB/s, the best seen there) and 5-7 % behind on fast ones -- which is what a tuner is for.
-# Late round 3 (lean staging, packed arithmetic: small tiles had been VALU-bound): the default became the 32-residue tile at
-# 5 workgroups per CU (20 KB), and the candidates are its neighbours -- 4 per CU (24 KB: +1 % on slow buffers and on some
+# only for a clear (>= 1 %) gain in the MEAN launch time.  Pattern kernel (N % 16 == 0): KB of idle LDS per workgroup
+# (only lowers the number of resident workgroups per CU: fewer concurrent store streams) and column residues per tile.
+# Around the default -- 32-residue tiles at 5 workgroups per CU -- sit 4 per CU (24 KB: +1 % on slow buffers and on some
 # fast ones, -3 % on others), 6 per CU (16 KB), 3 per CU (36 KB: +1-4 % on slow and medium buffers, -4 % on fast ones), the
-# 16-residue tile, and the two earlier defaults (profiles/r03_k1_ab_lean_*.log).
+# 16-residue tile, the 64-residue tile and the 128-residue tile + 8 KB that was the default until late round 3
+# (profiles/r03_k1_ab_lean_*.log).
 _K1_CANDIDATE_PATTERN = (
     {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 0},      # the default: 32-residue tiles, 5 workgroups per CU
     {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 32},
