@@ -70,7 +70,8 @@ typedef struct ps_k1_config {
     int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 20) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
-    int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32) */
+    int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32; 128 for a launch
+                             that writes the mask plane only) */
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
     int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
