@@ -4,7 +4,8 @@ all are loaded with ctypes, and ps_pairwise_distance_f32 of each is timed in int
 buffers.  Usage: python3 tools/k1_ab_libs.py libA.so libB.so [libC.so ...] [A:N ...]   (default shapes: 37:128 25:128
 14:256); every argument ending in .so is a library, the others are shapes; the first library is the bit reference.
 K1_CFGS="jt=32,lds_pad_kb=24;jt=64" in the environment times those ps_k1_config settings (through
-ps_pairwise_distance_cfg_f32) next to the default, on K1_NBUF (default 1) output-buffer pairs per shape."""
+ps_pairwise_distance_cfg_f32) next to the default, on K1_NBUF (default 1) output-buffer pairs per shape (K1_HOLD=1 keeps every pair allocated, so that the
+pairs are distinct allocations rather than one block handed back by the caching allocator)."""
 import ctypes
 import os
 import sys
@@ -27,6 +28,7 @@ class Cfg(ctypes.Structure):
 for lib in libs:
     lib.ps_pairwise_distance_cfg_f32.restype = i32
     lib.ps_pairwise_distance_cfg_f32.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, ctypes.POINTER(Cfg), vp]
+held = []
 specs = [""] + [c for c in os.environ.get("K1_CFGS", "").split(";") if c]
 nbuf = int(os.environ.get("K1_NBUF", "1"))
 
@@ -81,5 +83,7 @@ for A, N, *rest in shapes:       # "A:N" or "A:N:B"
                     tot[k] += e0.elapsed_time(e1) / 5
             print(f"A={A:3d} N={N:4d} B={B:4d} buf{kb} [{spec or 'default':24s}] " + "  ".join(f"{n} {nb / (t / R) / 1e9:5.2f}" for n, t in zip(names, tot)) +
                   f"  TB/s (mean of {R} rounds)   same bits: {same}", flush=True)
+        if os.environ.get("K1_HOLD"):      # keep the pair alive: the next one is then a NEW allocation, not this block handed back
+            held.append((d, m))
         del d, m
     del xyz, mask
