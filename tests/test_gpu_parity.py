@@ -260,6 +260,41 @@ def test_k1_store_policy_variants_agree(SB):
         _lib.set_tuning("k1_jt", jt0)
 
 
+def test_k1_pattern_kernel_single_plane_launches(SB):
+    """The pattern kernel with only one plane requested: a distance-only launch and a mask-only launch (which stages no
+    coordinates and takes 128-residue tiles by default) reproduce the planes of the fused launch bit for bit, at every tile
+    length, with and without an atom mask, for row ranges and several rows per workgroup."""
+    from protstruc_amd import _lib, ops
+    keys = ("k1_jt", "k1_rows_per_block", "k1_lds_pad_kb")
+    saved = {k: _lib.get_tuning(k) for k in keys}
+    try:
+        for (B, N) in [(3, 16), (2, 48), (2, 208), (1, 256)]:
+            xyz, mask = synth(300 + N, B, N)
+            xyz[0, N // 3] = float("nan")
+            xg, mg = xyz.cuda(), mask.cuda()
+            for am in (mg, None):
+                for k, v in saved.items():
+                    _lib.set_tuning(k, v)
+                assert _lib.k1_plan(B, N, 15)["family"] == "pattern"
+                ref_d, ref_m = ops.pairwise_distance(xg, am)
+                for jt, rows in [(0, 1), (16, 1), (32, 3), (64, 1), (128, 2), (16, 32)]:
+                    _lib.set_tuning("k1_jt", jt)
+                    _lib.set_tuning("k1_rows_per_block", rows)
+                    d0, none_m = ops.pairwise_distance(xg, am, want_mask=False)
+                    none_d, m1 = ops.pairwise_distance(xg, am, want_dist=False)
+                    assert none_m is None and none_d is None
+                    assert torch.equal(d0.view(torch.int32), ref_d.view(torch.int32)), (B, N, jt, rows)
+                    assert torch.equal(m1, ref_m), (B, N, jt, rows)
+                    r0, r1 = N // 4, N - 1
+                    cd, _ = ops.pairwise_distance(xg, am, row_begin=r0, row_end=r1, compact=True, want_mask=False)
+                    _, cm = ops.pairwise_distance(xg, am, row_begin=r0, row_end=r1, compact=True, want_dist=False)
+                    assert torch.equal(cd.view(torch.int32), ref_d[:, r0:r1].contiguous().view(torch.int32))
+                    assert torch.equal(cm, ref_m[:, r0:r1])
+    finally:
+        for k, v in saved.items():
+            _lib.set_tuning(k, v)
+
+
 @pytest.mark.parametrize("exact", [0, 1])
 def test_k1_flat_kernel_bit_identical_to_slot_decode(SB, exact):
     """The flat pattern kernel (any N >= 16) against the slot-decode kernel: same bits, nothing written outside the
