@@ -48,7 +48,10 @@ measured with HIP events on the launch stream inside the timed region.
 region: MI355X allocations come in a faster and a slower class,
 and this is how the line shows which one this run drew; ``roofline.allocation_lottery``
 (N = 1, informational, measured after everything else) times the same kernel on
-four fresh allocations of the process.  ``roofline.wall_minus_kernel_ms_per_step``
+four fresh allocations of the process and then times the fastest of them exactly
+like the headline (``kept_pair_timed_like_the_headline``: what a caller who uses
+``ops.allocate_fast_outputs`` gets); the headline itself is always measured on the
+first allocation ``torch.empty`` returned.  ``roofline.wall_minus_kernel_ms_per_step``
 is the host-side gap between the wall clock of the timed region and the kernels'
 own event time (timing events are created before the timed region).
 ``cpu_baseline`` (N = 1 only) times the CPU oracle -- the same ATen op sequence
