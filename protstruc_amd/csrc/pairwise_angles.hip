@@ -18,6 +18,10 @@
 // is where the 1e-5 parity tolerance is spent.
 #include "ps_common.hpp"
 
+#include <cstdint>
+#include <initializer_list>
+#include <type_traits>
+
 namespace {
 
 struct AtomSel {
@@ -156,6 +160,96 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     }
 }
 
+// The same featuriser with NC (2 or 4) consecutive column residues per lane (N % NC == 0, planes aligned to 4 * NC bytes,
+// mask planes to NC bytes): every float plane is written with 4 * NC-byte stores and every mask plane with one NC-byte
+// store per row -- 1 / NC of the store instructions of the one-column kernel above (nine stores per pair there: three of
+// them single bytes).  A wave owns 64 * NC columns x its own rows: the four waves of a workgroup take different row pairs
+// of the chunk, so everything on the row side stays wave-uniform (scalar loads).  Same arithmetic per pair: same bits.
+template <bool EXACT, int NC>
+__global__ __launch_bounds__(256) void k3_inter_residue_geometry_cols(
+    const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
+    float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
+    float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
+    int A, int IR, int n_tiles, int n_chunks) {
+    static_assert(NC == 2 || NC == 4, "columns per lane");
+    typedef typename std::conditional<NC == 4, float4, float2>::type fvec;
+    typedef typename std::conditional<NC == 4, uint32_t, uint16_t>::type mvec;
+    const unsigned w = blockIdx.x;
+    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
+    const int b = (int)(rest / (unsigned)n_chunks);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int j0 = ((int)tile * 64 + lane) * NC;
+    const int i0 = (int)(rest % (unsigned)n_chunks) * IR, i1 = min(i0 + IR, N);   // IR and N even: whole row pairs
+    const bool live = j0 < N;                                                      // N % NC == 0: a lane's columns are in or out
+    const int jc = live ? j0 : N - NC;
+    f3 ca_j[NC], o_j[NC], cb_j[NC];
+    uint32_t mj_ca = 0x01010101u, mj_o = 0x01010101u, mj_cb = 0x01010101u;       // byte c = mask of column jc + c
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float* sj = xyz + ((size_t)b * N + jc + c) * (size_t)A * 3;
+        ca_j[c] = load3(sj + 3); o_j[c] = load3(sj + 9); cb_j[c] = load3(sj + 12);
+    }
+    if (amask) {
+        mj_ca = mj_o = mj_cb = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint8_t* mj = amask + ((size_t)b * N + jc + c) * A;
+            mj_ca |= (mj[1] != 0 ? 1u : 0u) << (8 * c);
+            mj_o |= (mj[3] != 0 ? 1u : 0u) << (8 * c);
+            mj_cb |= (mj[4] != 0 ? 1u : 0u) << (8 * c);
+        }
+    }
+    for (int i = i0 + 2 * wave; i + 1 < i1; i += 8) {
+        const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;   // wave-uniform
+        const float* s1 = s0 + (size_t)A * 3;
+        const f3v nv = mk3v(load3(s0), load3(s1)), cav = mk3v(load3(s0 + 3), load3(s1 + 3));
+        const f3v cbv = mk3v(load3(s0 + 12), load3(s1 + 12));
+        bool n0 = true, a0 = true, c0 = true, n1 = true, a1 = true, c1 = true;    // row masks of N, CA, CB (rows i, i + 1)
+        if (amask) {
+            const uint8_t* mi = amask + ((size_t)b * N + i) * A;
+            n0 = mi[0] != 0; a0 = mi[1] != 0; c0 = mi[4] != 0;
+            n1 = mi[A] != 0; a1 = mi[A + 1] != 0; c1 = mi[A + 4] != 0;
+        }
+        if (!live) continue;
+        const size_t o = ((size_t)b * N + i) * N + j0;     // multiple of NC
+        auto put = [&](float* plane, const f32x2 (&v)[NC]) {
+            if constexpr (NC == 4) {
+                *reinterpret_cast<float4*>(plane + o) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
+                *reinterpret_cast<float4*>(plane + o + N) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+            } else {
+                *reinterpret_cast<float2*>(plane + o) = make_float2(v[0].x, v[1].x);
+                *reinterpret_cast<float2*>(plane + o + N) = make_float2(v[0].y, v[1].y);
+            }
+        };
+        // plane by plane, so that only one plane's results are live at a time
+        f32x2 v[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(cav, mk3v(ca_j[c], ca_j[c]));
+        put(d_ca, v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(cbv, mk3v(cb_j[c], cb_j[c]));
+        put(d_cb, v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(nv, mk3v(o_j[c], o_j[c]));
+        put(d_no, v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = angle3v(cav, cbv, mk3v(cb_j[c], cb_j[c]));
+        put(phi, v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = dihedral4v_k3(cav, cbv, mk3v(ca_j[c], ca_j[c]), mk3v(cb_j[c], cb_j[c]));   // protstruc.py:811
+        put(omega, v);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) v[c] = dihedral4v_k3(nv, cav, cbv, mk3v(cb_j[c], cb_j[c]));
+        put(theta, v);
+        *reinterpret_cast<mvec*>(m_ca + o) = (mvec)(a0 ? mj_ca : 0u);
+        *reinterpret_cast<mvec*>(m_ca + o + N) = (mvec)(a1 ? mj_ca : 0u);
+        *reinterpret_cast<mvec*>(m_cb + o) = (mvec)(c0 ? mj_cb : 0u);
+        *reinterpret_cast<mvec*>(m_cb + o + N) = (mvec)(c1 ? mj_cb : 0u);
+        *reinterpret_cast<mvec*>(m_no + o) = (mvec)(n0 ? mj_o : 0u);
+        *reinterpret_cast<mvec*>(m_no + o + N) = (mvec)(n1 ? mj_o : 0u);
+    }
+}
+
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
            int out_rows, int out_row_origin, hipStream_t s) {
@@ -212,6 +306,28 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
         return (int)hipErrorInvalidValue;
     if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1)) return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
+    {   // two columns per lane where every store is aligned: N even, 8-byte (masks: 2-byte) aligned planes
+        constexpr int NC = 2;
+        uintptr_t al = 0;
+        for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
+                              (const void*)theta, (const void*)phi})
+            al |= reinterpret_cast<uintptr_t>(p) & (4u * NC - 1u);
+        for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
+            al |= reinterpret_cast<uintptr_t>(p) & (NC - 1u);
+        if (N % NC == 0 && al == 0) {
+            const int IRq = 32;   // 4 waves x 4 trips of a row pair
+            const int n_tiles = (N + 64 * NC - 1) / (64 * NC), n_chunks = (N + IRq - 1) / IRq;
+            const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+            if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+            if (exact_sqrt)
+                return ps_launch(k3_inter_residue_geometry_cols<true, NC>, dim3((unsigned)n_wg), dim3(256), 0,
+                                 reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
+                                 d_ca_mask, d_cb_mask, d_no_mask, N, A, IRq, n_tiles, n_chunks);
+            return ps_launch(k3_inter_residue_geometry_cols<false, NC>, dim3((unsigned)n_wg), dim3(256), 0,
+                             reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
+                             d_ca_mask, d_cb_mask, d_no_mask, N, A, IRq, n_tiles, n_chunks);
+        }
+    }
     const int IR = 16;
     const int n_tiles = (N + 255) / 256, n_chunks = (N + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;

@@ -1442,12 +1442,13 @@ def test_inter_residue_geometry_golden(SB):
             assert_close(v, g[k], bad_frac=1.0 / g[k].numel())
 
 
-def test_inter_residue_geometry_matches_unfused_kernels(SB):
+@pytest.mark.parametrize("N", [100, 101, 258, 34])   # even lengths: two columns per lane (one / three column tiles, a
+def test_inter_residue_geometry_matches_unfused_kernels(SB, N):   # partly idle wave); odd: the one-column kernel
     """The fused featuriser must equal the K1 slices -- in BOTH square-root modes of the device (it takes the mode K1
     takes: the hardware square root by default, the correctly rounded one after set_exact_sqrt(True)), the two modes
     within 1 ulp of each other -- and the K3 calls it replaces, bit for bit."""
     from protstruc_amd import ops
-    xyz, mask = synth(77, 3, 100)
+    xyz, mask = synth(77, 3, N)
     sb = SB.from_xyz(xyz, mask)
     was = ops.get_exact_sqrt()
     geos = {}
