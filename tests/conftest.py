@@ -35,6 +35,15 @@ def pytest_sessionstart(session):
     markexpr = (session.config.option.markexpr or "").strip()
     if "not gpu" in markexpr or os.environ.get("PS_NO_REHEARSAL"):
         return
+    # A run that cannot select a rehearsal test (a -k expression without negation that names none of them, or explicit
+    # test files other than theirs) does not pay for the child processes.
+    tokens = ("multirank", "rehears", "bench_gpus", "c_abi", "c99", "consumer", "rank", "gloo", "rccl", "rowshard", "world")
+    kw = (session.config.option.keyword or "").strip().lower()
+    if kw and "not " not in kw and not any(t in kw for t in tokens):
+        return
+    files = [a for a in session.config.args if a.endswith(".py") or ".py::" in a]
+    if files and not any(("multirank" in f or "c_abi" in f) for f in files):
+        return
     try:
         if torch.cuda.device_count() < 1:
             return
