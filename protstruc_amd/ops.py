@@ -267,7 +267,7 @@ def allocate_fast_outputs(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] =
     output landed in -- 6.0 to 7.1 TB/s for the same kernel in one process ("fast and slow
     allocations") -- and a caller who keeps its output buffers for many steps inherits that luck for the whole run.
     This helper allocates the (dist, mask) pair ``candidates`` times (all held at once: candidates x 1125 B per
-    residue pair), times nine launches on each (three interleaved rounds), returns the fastest pair and releases the others.
+    residue pair; fewer if the device runs out of memory), times nine launches on each (three interleaved rounds), returns the fastest pair and releases the others.
     Returns ``(dist, mask, report)``; results written into the buffers are the same whichever pair is chosen."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
@@ -275,8 +275,14 @@ def allocate_fast_outputs(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] =
     pairs = []
     with _on(xyz.device):
         for _ in range(max(1, int(candidates))):
-            pairs.append((torch.empty(shape, dtype=torch.float32, device=xyz.device),
-                          torch.empty(shape, dtype=torch.bool, device=xyz.device)))
+            try:
+                d_ = torch.empty(shape, dtype=torch.float32, device=xyz.device)
+                pairs.append((d_, torch.empty(shape, dtype=torch.bool, device=xyz.device)))
+            except torch.cuda.OutOfMemoryError:      # a shape that does not fit `candidates` times: choose among what did fit
+                d_ = None
+                if not pairs:
+                    raise
+                break
         pairwise_distance(xyz, atom_mask, out_dist=pairs[0][0], out_mask=pairs[0][1])   # warm-up
         t_end = time.perf_counter() + 0.12
         while time.perf_counter() < t_end:
