@@ -1,7 +1,9 @@
 """Host-side PDB reader -- CPU tests.  Numeric parity with biotite is unpinned (biotite is
 not installed anywhere this runs); the pins are the residue counts the reference's tests / survey state."""
+import math
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -130,3 +132,93 @@ def test_two_termini_per_structure_like_the_reference_test():
         first_of_second_chain = int((chain_idx[b, :n] == 1).nonzero()[0])
         assert nterm[b].nonzero().flatten().tolist() == [0, first_of_second_chain]
         assert cterm[b].nonzero().flatten().tolist() == [first_of_second_chain - 1, n - 1]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Round 4: every pin the reference holds for the reader.  The tutorial entries under the reference's docs/tutorials/
+# (1REX, 4EOT, 4uuj; committed here as data under tests/golden/) are what its network tests and notebooks parse, and
+# those state what comes out: tests/test_StructureBatch.py:123-128 (1REX -> 130 residues), :158-163 ([130, 184]),
+# docs/tutorials/ramachandran_plot.ipynb cells 3-8 ((2, 184, 3); 128 / 180 residues valid for phi / psi, equal to
+# biotite's own count), pairwise_distance_matrix.ipynb cells 3-5, k_nearest_residues.ipynb cell 4 (4uuj -> 545).
+# The GPU twins of these are in tests/test_gpu_reference_suite.py.
+TUTORIAL = [os.path.join(G, n) for n in ("1REX.pdb", "4EOT.pdb")]
+
+
+def test_tutorial_entries_counts_the_reference_states():
+    xyz, mask, chain_idx, chain_ids, seq, residue_idx = read_batch(TUTORIAL)
+    assert xyz.shape == (2, 184, 15, 3)                                  # ramachandran_plot.ipynb cell 3: (2, 184, 3)
+    assert chain_ids == [["A"], ["A", "B"]]
+    sb = StructureBatch.from_pdb(TUTORIAL, device="cpu")
+    assert sb.get_total_lengths().tolist() == [130, 184]                 # test_StructureBatch.py:158-163
+    assert PDB.read_pdb(TUTORIAL[0]).n_residues == 130                   # test_StructureBatch.py:123-128
+    assert PDB.read_pdb(os.path.join(G, "4uuj.pdb")).n_residues == 545   # k_nearest_residues.ipynb cell 4
+    assert PDB.read_pdb(os.path.join(G, "4uuj.pdb")).get_chain_ids() == ["C", "A", "B"]   # file order; cell 1 names A heavy, B light, C antigen
+
+
+def test_tutorial_entries_valid_phi_psi_counts_through_the_oracle():
+    """ramachandran_plot.ipynb cells 3-8: 128 / 180 residues have a valid (phi, psi) pair, the reference's own count
+    and biotite's.  Here: the reader's tensors through the CPU oracle's backbone_dihedrals."""
+    from oracle import protstruc_oracle as O
+    xyz, mask, chain_idx, chain_ids, seq, residue_idx = read_batch(TUTORIAL)
+    dih, dmask = O.backbone_dihedrals(xyz, chain_idx, mask.any(-1))
+    assert dih.shape == (2, 184, 3) and dmask.shape == (2, 184, 3)
+    valid = dmask[:, :, [0, 1]].all(-1)
+    assert valid.sum(1).tolist() == [128, 180]
+    assert not torch.isnan(dih[:, :, :2][valid]).any()
+    assert (dih[:, :, :2][valid].abs() <= math.pi).all()
+
+
+def _canonical_atom_records(path):
+    """The file's model-1, first-altloc ATOM / HETATM records of canonical (or substituted) residues whose atom name is
+    in that residue's 15-slot table -- by plain column slicing, independently of protstruc_amd.pdb's parser (only the
+    reference's two data tables are shared: the substitution table general.py:109-124 and the slot table :149-171)."""
+    from protstruc_amd.pdb import ATOM_SLOT as SLOT, SUBSTITUTIONS as SUB
+    out, first_altloc = [], {}
+    with open(path) as fh:
+        for line in fh:
+            if line.startswith("ENDMDL"):
+                break                                                # model 1 only (reference pdb.py:66)
+            if line[:6] not in ("ATOM  ", "HETATM"):
+                continue
+            name = line[17:20].strip()
+            name = SUB.get(name, name)
+            atom = line[12:16].strip()
+            if name not in SLOT or atom not in SLOT[name]:
+                continue
+            res = (line[21], line[22:26], line[26])                 # chain, residue number, insertion code (raw text)
+            alt = line[16]
+            if alt != " " and first_altloc.setdefault(res, alt) != alt:
+                continue
+            out.append((res, name, atom, np.array([line[30:38], line[38:46], line[46:54]], dtype=np.float64)))
+    return out
+
+
+@pytest.mark.parametrize("name", ["15c8_HL.pdb", "6dc4.pdb", "1ad0_DC.pdb", "5cjx_HL.pdb", "1a3r_HL.pdb", "1a6v_HL.pdb",
+                                  "1a6v_JN.pdb", "1REX.pdb", "4EOT.pdb", "4uuj.pdb"])
+def test_every_atom_record_lands_in_exactly_one_slot(name):
+    """Conservation (needs no biotite): every qualifying ATOM record of the file appears in exactly one (residue, slot)
+    with float32(columns 31-54) as its coordinates, nothing else is set, and residues keep the file's order."""
+    from protstruc_amd.pdb import ATOM_SLOT as SLOT
+    path = os.path.join(G, name)
+    recs = _canonical_atom_records(path)
+    p = PDB.read_pdb(path)
+    xyz, mask = p.get_atom_xyz()
+    assert int(mask.sum()) == len(recs) > 0                          # as many set slots as qualifying records
+    seen = torch.zeros_like(mask)
+    order, last = [], None
+    for res, rname, atom, coord in recs:
+        key = (res[0], int(res[1]), res[2].strip())
+        idx = p.cri2idx[key]
+        slot = SLOT[rname][atom]
+        assert p.name_of[idx] == rname and p.chain_of[idx] == res[0] and p.number_of[idx] == int(res[1])
+        assert mask[idx, slot] and not seen[idx, slot], (name, res, atom)   # in exactly one slot, no slot hit twice
+        seen[idx, slot] = True
+        assert np.array_equal(xyz[idx, slot].numpy(), coord.astype(np.float32)), (name, res, atom)
+        if idx != last:
+            order.append(idx)
+            last = idx
+    assert torch.equal(seen, mask)                                   # nothing is set that no record accounts for
+    assert order == sorted(order) and len(set(order)) == len(order)  # file order, every residue one contiguous run
+    with_atoms = mask.any(-1).nonzero().flatten().tolist()
+    assert with_atoms == order                                       # residues without records are the UNK fillers only
+    assert all(p.name_of[i] == "UNK" for i in range(p.n_residues) if i not in set(order))

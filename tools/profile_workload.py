@@ -8,6 +8,8 @@
     k1      the headline K1 launch (B=64, N=512, A=15)
     k1s     K1 at the small atom counts, ~4 GB of output each: (A, N) = (5, 512), (5, 500), (5, 501), (3, 501), (1, 512),
             (2, 512) through the default dispatch (row-phase kernel)
+    k5      K5 / K6 / K4 at BASELINE config 5's shape (B=256, N=384): diffuse_xyz (in-kernel Philox), diffuse_xyz with
+            injected noise, standardize, backbone_orientations, the fused diffuse + frames step
 Every kernel is launched `reps` times (default 10) after 2 warm-ups, nothing else runs on the GPU."""
 import os
 import sys
@@ -43,6 +45,22 @@ if what == "k3":
     repeat(lambda: sb.pairwise_dihedrals(["N", "CA", "CB"], ["CB"]))
     repeat(lambda: sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
     repeat(lambda: sb.inter_residue_geometry())
+elif what == "k5":
+    xyz, mask = synth(256, 384)
+    sb = StructureBatch.from_xyz(xyz, mask).manual_seed(1)
+    beta = torch.full((256,), 0.01, device="cuda")
+    noise = torch.randn(256, 384, 15, 3, device="cuda")
+    rot = torch.empty(256, 384, 3, 3, device="cuda")
+    tr = torch.empty(256, 384, 3, device="cuda")
+    repeat(lambda: sb.diffuse_xyz(beta))
+    repeat(lambda: sb.diffuse_xyz(beta, noise=noise))
+
+    def restd():
+        sb._standardized = False
+        sb.standardize()
+    repeat(restd)
+    repeat(lambda: sb.backbone_orientations())
+    repeat(lambda: sb.diffuse_xyz_and_frames(beta, out_rot=rot, out_trans=tr))
 elif what == "k1a":
     for A, N in ((14, 256), (37, 128)):
         B = max(1, int(8e9 / (N * N * A * A * 5)))
