@@ -18,6 +18,7 @@
 // is where the 1e-5 parity tolerance is spent.
 #include "ps_common.hpp"
 
+#include <algorithm>
 #include <cstdint>
 #include <initializer_list>
 #include <type_traits>
@@ -27,6 +28,26 @@ namespace {
 struct AtomSel {
     int atom[4];
 };
+
+typedef float k3_f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t k3_u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t k3_u32x2 __attribute__((ext_vector_type(2)));
+
+// CUs of the device the calling thread has current (cached per ordinal; a constant of the device, not library state)
+inline int k3_cu_count() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
+    if (n <= 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cached[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
+}
+
+constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
+constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
 
 template <int NP, int SRC>
 __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restrict__ xyz, float* __restrict__ out,
@@ -83,69 +104,153 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     }
 }
 
-// The same sweep with TWO consecutive column residues per lane (N even, 8-byte aligned output): 8-byte stores, half the store
-// instructions, two independent arithmetic chains per lane.  A workgroup covers 512 columns.  Same arithmetic per pair.
-template <int NP, int SRC>
-__global__ __launch_bounds__(256) void k3_pairwise_angles_c2(const float* __restrict__ xyz, float* __restrict__ out,
-                                                             int N, int A, AtomSel sel, int row_begin, int row_end,
-                                                             int out_rows, int out_row_origin, int IR, int n_tiles,
-                                                             int n_chunks) {
-    const unsigned w = blockIdx.x;
-    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
-    const int b = (int)(rest / (unsigned)n_chunks);
-    const int j = ((int)tile * 256 + (int)threadIdx.x) * 2;
-    const int i0 = row_begin + (int)(rest % (unsigned)n_chunks) * IR;
-    const int i1 = min(i0 + IR, row_end);
-    const bool live = j < N;                       // N even: both columns are in or out
-    const int jc = live ? j : N - 2;
-    f3 pj[2][NP];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const float* sj = xyz + ((size_t)b * N + jc + c) * (size_t)A * 3;
-#pragma unroll
-        for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
-    }
-    int i = i0;
-    for (; i + 1 < i1; i += 2) {
-        const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
-        const float* s1 = s0 + (size_t)A * 3;
-        f3v pi[NP];
+// The sweep for even N (round 4): ONE 1024-thread workgroup per CU, NC = 2 or 4 consecutive column residues per lane
+// (8- or 16-byte stores), two rows per trip in the halves of float2 registers.
+//   * Work list: task t = (b * n_strips + strip) * n_chunks + chunk = CH rows x one strip of 64 * NC columns of one
+//     structure.  A workgroup owns a contiguous range of it (1 / #CUs of the list); its LDS request keeps a second
+//     workgroup off the CU, so every CU gets the same share whatever the dispatcher does.
+//   * The row-side points of a (b, strip) segment are staged ONCE in LDS, pair-interleaved: one broadcast ds_read_b64 /
+//     b128 delivers {row 2r, row 2r + 1} of a component already in the packed layout -- no scalar loads, no s_waitcnt on
+//     SMEM and no SGPR -> VGPR moves inside the loop (the kernels before staged nothing: rows came by s_load per trip).
+//   * The 16 waves PULL tasks from an LDS counter.  The SIMD arbiter serves its oldest wave first: with equal static
+//     shares the four waves of a SIMD finish one after the other (18 / 28 / 38 / 47 us at config 3) and the last one runs
+//     alone at half the issue rate; pulling lets the favoured waves take more tasks and all of them end together.
+//   * Stores are write-through (sc1): the 134 MB of config 3 would otherwise leave up to 32 MB dirty in the L2s for the
+//     end-of-kernel write-back, which is serial with everything (3-4 us of 57).
+//   * The arithmetic of the NC columns is evaluated step by step across the columns (dihedral4v_k3_n, angle3v_n).
+// Same operations per pair as the one-column kernel above: same bits.
+template <int NP, int SRC, int NC>
+__global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
+                                                 AtomSel sel, int row_begin, int row_end, int out_rows,
+                                                 int out_row_origin, int CH, int n_strips, int n_chunks,
+                                                 unsigned n_tasks, unsigned tasks_per_wg) {
+    static_assert(NC == 2 || NC == 4, "columns per lane");
+    constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));   // points taken from the row residue
+    constexpr int NPIq = NPI > 0 ? NPI : 1;
+    constexpr int POL = 16;                       // sc1: write-through
+    extern __shared__ f32x2 k3_rowbuf[];          // [row pair][row point][xyz] of the current segment
+    __shared__ unsigned next_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_waves = (int)(blockDim.x >> 6);
+    const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
+    if (t0 >= t1) return;                         // whole workgroup
+    int amap[NPIq];
+    {
+        int q = 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k)
-            pi[k] = ((SRC >> k) & 1) ? mk3v(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f))
-                                     : mk3v(load3(s0 + sel.atom[k] * 3), load3(s1 + sel.atom[k] * 3));
-        f32x2 v[2];
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f3v p[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? mk3v(pj[c][k], pj[c][k]) : pi[k];
-            if constexpr (NP == 4)
-                v[c] = dihedral4v_k3(p[0], p[1], p[2], p[3]);
-            else
-                v[c] = angle3v(p[0], p[1], p[2]);
-        }
-        if (live) {
-            float* o = out + ((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j;
-            *reinterpret_cast<float2*>(o) = make_float2(v[0].x, v[1].x);
-            *reinterpret_cast<float2*>(o + N) = make_float2(v[0].y, v[1].y);
-        }
+            if (!((SRC >> k) & 1)) amap[q++] = sel.atom[k];
+        if (NPI == 0) amap[0] = 0;
     }
-    for (; i < i1; ++i) {
-        const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
-        float v[2];
+    const int row_bytes = N * 4;
+    int staged_b = -1, staged_lo = -1, staged_hi = -1;
+    for (unsigned g = t0 / (unsigned)n_chunks; g <= (t1 - 1u) / (unsigned)n_chunks; ++g) {   // g = b * n_strips + strip
+        const int c_lo = (int)(max(t0, g * (unsigned)n_chunks) - g * (unsigned)n_chunks);
+        const int c_hi = (int)(min(t1, (g + 1u) * (unsigned)n_chunks) - g * (unsigned)n_chunks);
+        const int b = (int)(g / (unsigned)n_strips), strip = (int)(g % (unsigned)n_strips);
+        const int r_lo = row_begin + c_lo * CH, r_hi = min(row_begin + c_hi * CH, row_end);
+        const float* xb = xyz + (size_t)b * N * (size_t)A * 3;   // uniform
+        __syncthreads();                                          // the previous segment's readers are done
+        if (NPI > 0 && (b != staged_b || r_lo != staged_lo || r_hi != staged_hi)) {
+            float* rb = reinterpret_cast<float*>(k3_rowbuf);
+            const int n_el = (r_hi - r_lo) * NPI * 3;
+            for (int e = (int)threadIdx.x; e < n_el; e += (int)blockDim.x) {
+                const int row = e / (NPI * 3), rem = e - row * (NPI * 3), q = rem / 3, c = rem - q * 3;
+                int at = amap[0];
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            f3 p[NP];
-#pragma unroll
-            for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[c][k] : load3(si + sel.atom[k] * 3);
-            if constexpr (NP == 4)
-                v[c] = dihedral4_k3(p[0], p[1], p[2], p[3]);
-            else
-                v[c] = angle3(p[0], p[1], p[2]);
+                for (int t = 1; t < NPI; ++t) at = (q == t) ? amap[t] : at;
+                rb[((((row >> 1) * NPI + q) * 3 + c) << 1) + (row & 1)] = xb[(size_t)(r_lo + row) * (size_t)A * 3 + at * 3 + c];
+            }
+            staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
         }
-        if (live)
-            *reinterpret_cast<float2*>(out + ((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j) = make_float2(v[0], v[1]);
+        if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
+        const int j0 = (strip * 64 + lane) * NC;
+        const bool live = j0 < N;                                 // N % NC == 0: a lane's columns are all in or all out
+        const int jc = live ? j0 : N - NC;
+        f3 pj[NC][NP];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float* sj = xb + (size_t)(jc + c) * (size_t)A * 3;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        // the segment's rows as one buffer: uniform base, the lane's constant byte offset, the row's byte offset as a scalar
+        float* obase = out + ((size_t)b * out_rows + (size_t)(r_lo - out_row_origin)) * N;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0xFFFFFFFFu, 0x00020000u);
+        const int lane_off = j0 * 4;
+        auto rows = [&](int r, f3v (&p)[NP]) {                    // r = row pair index inside the segment
+            int q = 0;
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if ((SRC >> k) & 1) {
+                    p[k] = mk3v(mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f));
+                } else {
+                    p[k] = f3v{k3_rowbuf[(r * NPI + q) * 3 + 0], k3_rowbuf[(r * NPI + q) * 3 + 1], k3_rowbuf[(r * NPI + q) * 3 + 2]};
+                    ++q;
+                }
+            }
+        };
+        int c = c_lo + wave;
+        while (c < c_hi) {
+            const int i0 = (c - c_lo) * CH;                       // rows relative to r_lo (CH is even: pairs stay aligned)
+            const int i1 = min(i0 + CH, r_hi - r_lo);
+            int i = i0;
+            for (; i + 1 < i1; i += 2) {
+                f3v cur[NP];
+                rows(i >> 1, cur);
+                f3v P[NP][NC];
+#pragma unroll
+                for (int k = 0; k < NP; ++k)
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) P[k][cc] = ((SRC >> k) & 1) ? mk3v(pj[cc][k], pj[cc][k]) : cur[k];
+                f32x2 v[NC];
+                if constexpr (NP == 4)
+                    dihedral4v_k3_n<NC>(P[0], P[1], P[2], P[3], v);
+                else
+                    angle3v_n<NC>(P[0], P[1], P[2], v);
+                // the results are pinned HERE: otherwise the compiler sinks the arithmetic into the `live` branch below, away
+                // from the scheduling barriers that interleave the columns' chains, and the chains serialise again
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
+                if (live) {
+                    const int so = i * row_bytes;
+                    if constexpr (NC == 4) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rsrc, lane_off, so, POL);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), rsrc, lane_off, so + row_bytes, POL);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lane_off, so, POL);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, lane_off, so + row_bytes, POL);
+                    }
+                }
+            }
+            if (i < i1) {   // odd last row of the row range
+                f3v cur[NP];
+                rows(i >> 1, cur);
+                float v[NC];
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    f3 p[NP];
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[cc][k] : mk3(cur[k].x.x, cur[k].y.x, cur[k].z.x);
+                    if constexpr (NP == 4)
+                        v[cc] = dihedral4_k3(p[0], p[1], p[2], p[3]);
+                    else
+                        v[cc] = angle3(p[0], p[1], p[2]);
+                }
+                if (live) {
+                    const int so = i * row_bytes;
+                    if constexpr (NC == 4)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0], v[1], v[2], v[3]}), rsrc, lane_off, so, POL);
+                    else
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0], v[1]}), rsrc, lane_off, so, POL);
+                }
+            }
+            unsigned nx = 0;
+            if (lane == 0) nx = atomicAdd(&next_task, 1u);
+            c = __builtin_amdgcn_readfirstlane((int)nx);
+        }
     }
 }
 
@@ -316,18 +421,63 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry_cols(
     }
 }
 
+// rows per task (even).  8 by default; fewer when the list would not give every CU's 16 waves a few tasks each
+inline int k3_rows_per_task(unsigned long long strips_x_structures, int rows, int cus) {
+    for (int ch : {8, 4}) {
+        const unsigned long long tasks = strips_x_structures * (unsigned long long)((rows + ch - 1) / ch);
+        if (tasks >= (unsigned long long)cus * 16 * 4) return ch;
+    }
+    return 2;
+}
+
+template <int NP, int SRC, int NC>
+int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
+                 int out_rows, int out_row_origin, hipStream_t s) {
+    constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
+    const int rows = row_end - row_begin, cus = k3_cu_count();
+    const int n_strips = (N + 64 * NC - 1) / (64 * NC);
+    const int CH = k3_rows_per_task((unsigned long long)n_strips * B, rows, cus);
+    const int n_chunks = (rows + CH - 1) / CH;
+    const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
+    if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    // every CU one workgroup; short lists: at least 4 tasks per workgroup (its 16 waves pull them)
+    const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + cus - 1) / cus, 4ull);
+    const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+    const size_t need = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8;   // one segment's rows, pair-interleaved
+    const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
+    static bool prepared = false;   // more than 64 KB of dynamic LDS has to be allowed once per kernel (idempotent)
+    if (!__atomic_load_n(&prepared, __ATOMIC_ACQUIRE)) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_sweep<NP, SRC, NC>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3_LDS_MAX);
+        if (e != hipSuccess) return (int)e;
+        __atomic_store_n(&prepared, true, __ATOMIC_RELEASE);
+    }
+    return ps_launch(k3_sweep<NP, SRC, NC>, dim3(grid), dim3(1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
+                     out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
+}
+
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
            int out_rows, int out_row_origin, hipStream_t s) {
-    const int IR = 16;
+    constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin;
-    if (N % 2 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0) {   // two columns per lane: dihedrals 60 -> 57 us at config 3
-        const int n_tiles = (N + 511) / 512, n_chunks = (rows + IR - 1) / IR;
-        const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
-        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        return ps_launch(k3_pairwise_angles_c2<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel,
-                         row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+    const uintptr_t al = reinterpret_cast<uintptr_t>(out);
+    // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS
+    const bool fits = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX;
+    // four columns per lane only where the instantiation keeps its registers (three or two column-side points of a
+    // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers)
+    constexpr bool NC4 = NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 12 || SRC == 15;
+    const bool ok4 = NC4 && fits && N % 4 == 0 && (al & 15u) == 0, ok2 = fits && N % 2 == 0 && (al & 7u) == 0;
+    if (ok4 || ok2) {
+        // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
+        const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
+        if constexpr (NC4) {
+            if (ok4 && (!ok2 || w4 <= w2))
+                return launch_sweep<NP, SRC, 4>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+        }
+        return launch_sweep<NP, SRC, 2>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
     }
+    const int IR = 16;
     const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;

@@ -321,6 +321,107 @@ __device__ __forceinline__ f32x2 dihedral4v_k3(f3v a, f3v b, f3v c, f3v d) {
     return atan2_k3_v(y, x);
 }
 
+// ---- NC column residues per lane: the same arithmetic STEP BY STEP across the columns ----
+// (round 4)  K3's time is the VALU's (tools/microbench/k3_valu_floor.hip), and a dependent v_pk_fma_f32 costs ~11 cycles
+// where an independent one costs 4: left to itself the compiler evaluates one column's Horner chain after the other with
+// an s_nop between the links.  Written across the columns, with a scheduling barrier after every link, the NC chains
+// interleave and the loop needs no s_nop at all: 0.60 -> 0.53 us per (4 columns x 2 rows) trip on one SIMD.  Per element
+// the operations and their order are those of atan2_k3 / acos_ps, hence the same bits.
+template <int NC>
+__device__ __forceinline__ void atan2_k3_vn(const f32x2 (&y)[NC], const f32x2 (&x)[NC], f32x2 (&r)[NC]) {
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 ax[NC], ay[NC], a[NC], s[NC], p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        ax[c] = f32x2{fabsf(x[c].x), fabsf(x[c].y)};
+        ay[c] = f32x2{fabsf(y[c].x), fabsf(y[c].y)};
+        const f32x2 mx = {fmaxf(fmaxf(ax[c].x, ay[c].x), 1.17549435e-38f), fmaxf(fmaxf(ax[c].y, ay[c].y), 1.17549435e-38f)};
+        const f32x2 mn = {fminf(ax[c].x, ay[c].x), fminf(ax[c].y, ay[c].y)};
+        a[c] = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) s[c] = a[c] * a[c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(k2(0.0028340641874819994f), s[c], k2(-0.016005029901862144f));
+    constexpr float co[7] = {0.042587608098983765f, -0.07495445758104324f, 0.10636754333972931f, -0.14202570915222168f,
+                             0.19992484152317047f, -0.3333306610584259f, 1.0f};
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(p[c], s[c], k2(co[t]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) r[c] = a[c] * p[c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 rq = k2(1.5707963267948966f) - r[c];
+        r[c].x = (ay[c].x > ax[c].x) ? rq.x : r[c].x;
+        r[c].y = (ay[c].y > ax[c].y) ? rq.y : r[c].y;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 rh = k2(3.141592653589793f) - r[c];
+        r[c].x = (__float_as_uint(x[c].x) >> 31) ? rh.x : r[c].x;
+        r[c].y = (__float_as_uint(x[c].y) >> 31) ? rh.y : r[c].y;
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        r[c] = __builtin_elementwise_fma(x[c], k2(0.0f), r[c]);
+        r[c] = f32x2{copysignf(r[c].x, y[c].x), copysignf(r[c].y, y[c].y)};
+    }
+}
+
+// dot3v with the leading `0 +` folded into the first product: fma(a, b, +0) rounds a * b once and adds +0, which is
+// bit for bit (0 + a * b) -- including the -0 -> +0 case the `0 +` exists for -- in one instruction instead of two.
+__device__ __forceinline__ f32x2 dot3v_f(f3v a, f3v b) {
+    const f32x2 px = __builtin_elementwise_fma(a.x, b.x, f32x2{0.0f, 0.0f}), py = a.y * b.y, pz = a.z * b.z;
+    return (px + py) + pz;
+}
+
+// dihedral4v_k3 for NC columns: the cross / dot part per column (independent work), then the NC atan2 chains together
+template <int NC>
+__device__ __forceinline__ void dihedral4v_k3_n(const f3v (&a)[NC], const f3v (&b)[NC], const f3v (&c)[NC],
+                                                const f3v (&d)[NC], f32x2 (&out)[NC]) {
+    f32x2 x[NC], y[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const f3v b0 = sub3v(a[q], b[q]), b1 = sub3v(c[q], b[q]), b2n = sub3v(c[q], d[q]);
+        const f3v n1 = cross3v(b0, b1), n2 = cross3v(b1, b2n);
+        const f32x2 nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
+        x[q] = dot3v_f(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+        y[q] = dot3v_f(n1, b2n);
+    }
+    atan2_k3_vn<NC>(y, x, out);
+}
+
+// acos_ps / angle3v for NC columns (same operations in the same order per element)
+template <int NC>
+__device__ __forceinline__ void acos_ps_vn(const f32x2 (&x)[NC], f32x2 (&r)[NC]) {
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 ax[NC], p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) ax[c] = f32x2{fabsf(x[c].x), fabsf(x[c].y)};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(k2(-0.0012624911f), ax[c], k2(0.0066700901f));
+    constexpr float co[6] = {-0.0170881256f, 0.0308918810f, -0.0501743046f, 0.0889789874f, -0.2145988016f, 1.5707963050f};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(p[c], ax[c], k2(co[t]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 t = k2(1.0f) - ax[c];
+        const f32x2 v = p[c] * f32x2{__builtin_amdgcn_sqrtf(t.x), __builtin_amdgcn_sqrtf(t.y)};
+        const f32x2 rh = k2(3.141592653589793f) - v;
+        r[c] = f32x2{(__float_as_uint(x[c].x) >> 31) ? rh.x : v.x, (__float_as_uint(x[c].y) >> 31) ? rh.y : v.y};
+    }
+}
+
 // acos_ps on both halves (same operations in the same order per element)
 __device__ __forceinline__ f32x2 acos_ps_v(f32x2 x) {
     const f32x2 ax = {fabsf(x.x), fabsf(x.y)};
@@ -379,6 +480,20 @@ __device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
     const f32x2 num = dot3v(ba, bc);
     const f32x2 q = dot3v(ba, ba) * dot3v(bc, bc);
     return acos_ps_v(num * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)});
+}
+
+template <int NC>
+__device__ __forceinline__ void angle3v_n(const f3v (&a)[NC], const f3v (&b)[NC], const f3v (&c)[NC], f32x2 (&out)[NC]) {
+    f32x2 cs[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const f3v ba = sub3v(a[q], b[q]), bc = sub3v(c[q], b[q]);
+        const f32x2 num = dot3v_f(ba, bc);
+        // squares are never -0, so the sums need no leading `0 +` (same bits as dot3v(ba, ba), dot3v(bc, bc))
+        const f32x2 den = ((ba.x * ba.x + ba.y * ba.y) + ba.z * ba.z) * ((bc.x * bc.x + bc.y * bc.y) + bc.z * bc.z);
+        cs[q] = num * f32x2{__builtin_amdgcn_rsqf(den.x), __builtin_amdgcn_rsqf(den.y)};
+    }
+    acos_ps_vn<NC>(cs, out);
 }
 
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {

@@ -1176,6 +1176,32 @@ def test_k3_row_ranges_compact_and_in_place(SB, N):
         ops.pairwise_angles(xg, [1, 4], [1, 4], 4, out=torch.empty(3, N, N + 1, device="cuda"))
 
 
+@pytest.mark.parametrize("N", [6, 64, 130, 256, 384, 512, 516])
+def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
+    """The per-CU sweep kernels (two / four column residues per lane, LDS-staged rows, pulled tasks, arithmetic
+    interleaved across the columns) evaluate the same operations per pair as the one-column kernel: same bits.  The
+    one-column kernel is reached through a 4-byte-misaligned output; full launches and an odd row range."""
+    from protstruc_amd import ops
+    B = 3
+    xyz, _ = synth(900 + N, B, N)
+    xyz[1, N // 2] = float("nan")                      # NaN rows and columns propagate identically
+    xyz[2, 1] = xyz[2, 0]                              # coincident residues: exact zeros / NaNs as the reference has them
+    xg = xyz.cuda()
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    splits = [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (4, [2], [0, 1, 2]), (4, [1], [4, 1, 0]), (4, [0, 1], [2, 3]),
+              (4, [0, 1, 2, 3], []), (4, [], [0, 1, 2, 3]), (3, [1, 4], [4]), (3, [1], [1, 4]), (3, [], [0, 1, 2]), (3, [4, 1, 0], [])]
+    for npts, si, sj in splits:
+        big = torch.full((B * N * N + 1,), 7.0, device="cuda")
+        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned -> one column per lane
+        fast = ops.pairwise_angles(xg, si, sj, npts)
+        assert same(fast, one), (npts, si, sj)
+        assert big[0] == 7.0
+        if N > 8:
+            r0, r1 = 3, N - 2                                                      # odd number of rows, odd first row
+            c = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True)
+            assert same(c, one[:, r0:r1]), (npts, si, sj)
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)
