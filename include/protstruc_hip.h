@@ -37,7 +37,7 @@ extern "C" {
 #define PS_RNG_STATE_WORDS 528
 
 /* ABI version of this header (bumped on any signature change); ps_abi_version() returns the library's. */
-#define PS_ABI_VERSION 3
+#define PS_ABI_VERSION 4
 int ps_abi_version(void);
 
 /* 0 for the product library.  1 for builds made with -DPS_EXPERIMENTS (tools/ only), which contain timing
@@ -178,13 +178,21 @@ int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_idx,
  * where p_k = xyz[b][ src[k] ? j : i ][ atom[k] ].  Rows i in
  * [row_begin, row_end) are produced into an (B, out_rows, N) buffer with the same
  * row addressing as K1.
+ * exact_angles (ABI 4), the angle counterpart of ps_k1_config.exact_sqrt:
+ *   0  the fast arithmetic: triple-product dihedral with one reciprocal square root, polynomial atan2 / acos, cosine
+ *      through v_rsq_f32 -- exact where the reference is exact (+0 diagonal, NaN positions), otherwise within the
+ *      conditioning gates of SURVEY hard part 3 (3.8e-6 of off-diagonal dihedrals more than 1e-5 from the reference
+ *      at unit scale, max 6.5e-5; profiles/r04_k3_error_stats.log);
+ *   1  the reference's order of operations (geometry.py:110-124, :64-66): three cross products, y / |b1| with a
+ *      correctly rounded square root and an IEEE division, the device library's atan2f / acosf.  No entry more than
+ *      1e-5 from the reference on well-conditioned inputs; about 2.5x the time.
  */
 int ps_pairwise_angles_f32(const float* xyz, float* out,
                            int B, int N, int A,
                            int n_points, const int* src, const int* atom,
                            int row_begin, int row_end,
                            int out_rows, int out_row_origin,
-                           void* stream);
+                           int exact_angles, void* stream);
 
 /*
  * K4 -- replaces StructureBatch.backbone_orientations + backbone_translations
@@ -281,12 +289,14 @@ int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, in
  * exact_sqrt: the square root of the three distance planes, as ps_k1_config.exact_sqrt -- 0: hardware v_sqrt_f32
  * (K1's default: the planes are then bit-identical to the slices of a default K1 launch), 1: correctly rounded
  * (bit-identical to K1 with exact_sqrt = 1).
+ * exact_angles (ABI 4): omega, theta and phi in the arithmetic ps_pairwise_angles_f32 uses for the same value (0 fast,
+ * 1 the reference's order of operations): the three planes equal the corresponding K3 launches bit for bit in both modes.
  */
 int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
                                   float* d_ca, float* d_cb, float* d_no,
                                   float* omega, float* theta, float* phi,
                                   uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask,
-                                  int B, int N, int A, int exact_sqrt, void* stream);
+                                  int B, int N, int A, int exact_sqrt, int exact_angles, void* stream);
 
 /*
  * Rigid-body ops.  ps_rigid_f32 replaces StructureBatch.translate,

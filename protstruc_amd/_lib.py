@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PROTSTRUC_AMD_LIB selects another build of the same sources (tools/ use the -DPS_EXPERIMENTS one)
 LIB_PATH = os.environ.get("PROTSTRUC_AMD_LIB") or os.path.join(_HERE, "lib", "libprotstruc_hip.so")
-EXPECTED_ABI = 3  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
+EXPECTED_ABI = 4  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
 
 
 class K1Config(ctypes.Structure):
@@ -46,7 +46,7 @@ SIGNATURES = {
     "ps_backbone_dihedrals_f32": (_c_int, [_c_f32p, _c_f32p, _c_u8p, _c_f32p, _c_u8p, _c_u8p, _c_u8p, _c_int, _c_int,
                                            _c_int, _c_stream]),
     "ps_pairwise_angles_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
-                                        ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _c_int, _c_stream]),
+                                        ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_stream]),
     "ps_pointwise_f32": (_c_int, [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_longlong, _c_stream]),
@@ -56,7 +56,7 @@ SIGNATURES = {
     "ps_diffusion_trajectory_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.c_void_p, _c_f32p,
                                              _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_inter_residue_geometry_f32": (_c_int, [_c_f32p, _c_u8p] + [_c_f32p] * 6 + [_c_u8p] * 3 + [_c_int, _c_int, _c_int,
-                                                                                                  _c_int, _c_stream]),
+                                                                                                  _c_int, _c_int, _c_stream]),
     "ps_rigid_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_center_of_mass_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_stream]),
     "ps_frames_to_backbone_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_f32p, _c_int, _c_int, _c_int, _c_stream]),
@@ -224,10 +224,13 @@ def k1_config_ref(idx):
     """``ctypes.byref`` of the cached configuration struct of device ``idx`` (the launch hot path: one dict lookup).
     The pair (struct, reference) is replaced, never mutated, when a setting changes; the library copies the struct by
     value before launching."""
-    ent = _k1_refs.get(idx)
+    ent = _k1_refs.get(idx)      # the hit path takes no lock: entries are replaced, never mutated
     if ent is None:
-        cfg = k1_config(idx)
-        ent = _k1_refs[idx] = (cfg, ctypes.byref(cfg))
+        with _k1_lock:           # look up, build and store under the lock set_tuning holds while it drops the entry,
+            ent = _k1_refs.get(idx)   # so a struct built from the settings before a change can never be cached after it
+            if ent is None:
+                cfg = k1_config(idx)
+                ent = _k1_refs[idx] = (cfg, ctypes.byref(cfg))
     return ent[1]
 
 
@@ -248,6 +251,25 @@ def set_tuning(key, value, device=None):
         _k1_entry(idx)[field] = value
         _k1_structs.pop(idx, None)     # the next launch builds a fresh struct; structs in flight stay as they were
         _k1_refs.pop(idx, None)
+
+
+# ---- K3 arithmetic mode: per device, host side (the library takes it per call, like exact_sqrt) ----------------------
+_angle_mode = {}   # device index -> 0 fast / 1 the reference's order of operations
+
+
+def set_exact_angles(flag, device=None):
+    with _k1_lock:
+        _angle_mode[_device_index(device)] = 1 if flag else 0
+
+
+def get_exact_angles(device=None):
+    idx = _device_index(device)
+    v = _angle_mode.get(idx)
+    if v is None:
+        v = 1 if os.environ.get("PROTSTRUC_AMD_EXACT_ANGLES", "0") not in ("", "0") else 0
+        with _k1_lock:
+            v = _angle_mode.setdefault(idx, v)
+    return v
 
 
 def get_tuning(key, device=None):

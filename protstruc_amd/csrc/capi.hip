@@ -6,7 +6,9 @@
 
 // 2: per-call K1 configuration (ps_k1_config, ps_pairwise_distance_cfg_f32) replaced the process-global
 //    ps_set_tuning / ps_get_tuning of version 1.
-// 3: ps_k1_plan_f32 (which kernel a K1 launch takes; host-only query).
+// 3: ps_k1_plan_f32 (which kernel a K1 launch takes; host-only query); ps_inter_residue_geometry_f32 takes exact_sqrt.
+// 4: ps_pairwise_angles_f32 and ps_inter_residue_geometry_f32 take exact_angles (0: fast arithmetic, 1: the reference's
+//    order of operations).
 extern "C" int ps_abi_version(void) { return PS_ABI_VERSION; }
 
 extern "C" const char* ps_error_string(int code) { return hipGetErrorString(static_cast<hipError_t>(code)); }

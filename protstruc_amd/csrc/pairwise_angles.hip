@@ -46,10 +46,11 @@ inline int k3_cu_count() {
     return n;
 }
 
+constexpr bool K3_FEATURISE_NC4 = false;          // four columns per lane spill ~70 registers in the featuriser: not used
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
 
-template <int NP, int SRC>
+template <int NP, int SRC, bool FAITHFUL>
 __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restrict__ xyz, float* __restrict__ out,
                                                           int N, int A, AtomSel sel, int row_begin, int row_end,
                                                           int out_rows, int out_row_origin, int IR, int n_tiles,
@@ -70,6 +71,21 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     for (int k = 0; k < NP; ++k) pj[k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
 
     int i = i0;
+    if constexpr (FAITHFUL) {   // the reference's order of operations (dihedral4_ref / angle3_ref), one row per trip
+        for (; i < i1; ++i) {
+            const float* si = xyz + ((size_t)b * N + i) * (size_t)A * 3;  // wave-uniform
+            f3 p[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[k] : load3(si + sel.atom[k] * 3);
+            float v;
+            if constexpr (NP == 4)
+                v = dihedral4_ref(p[0], p[1], p[2], p[3]);
+            else
+                v = angle3_ref(p[0], p[1], p[2]);
+            if (live) out[((size_t)b * out_rows + (size_t)(i - out_row_origin)) * N + j] = v;
+        }
+        return;
+    }
     // two rows per trip in the two halves of float2 registers -> packed v_pk_* math (bit-identical per element);
     // dihedrals and planar angles alike
     for (; i + 1 < i1; i += 2) {
@@ -257,7 +273,7 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
 // Fused trRosetta featuriser (reference protstruc.py:790-817): the three atom-pair planes of K1 that
 // inter_residue_geometry slices out (CA-CA, CB-CB, N-O), their masks, and the three K3 features, in
 // one sweep -- 27 bytes written per residue pair instead of 1125.  Same lane layout as K3.
-template <bool EXACT>
+template <bool EXACT, bool FAITHFUL>
 __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
@@ -293,10 +309,10 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         m_ca[o] = mi_ca & mj_ca;
         m_cb[o] = mi_cb & mj_cb;
         m_no[o] = mi_n & mj_o;
-        phi[o] = angle3(ca_i, cb_i, cb_j);
+        phi[o] = FAITHFUL ? angle3_ref(ca_i, cb_i, cb_j) : angle3(ca_i, cb_i, cb_j);
     };
     int i = i0;
-    for (; i + 1 < i1; i += 2) {  // two rows per trip: distances, planar angle and both dihedrals as packed float2 math
+    for (; !FAITHFUL && i + 1 < i1; i += 2) {  // two rows per trip: distances, planar angle and both dihedrals as packed float2 math
         f3 n0, ca0, cb0, n1, ca1, cb1;
         uint8_t a0, b0, c0, a1, b1, c1;
         row_scalars(i, n0, ca0, cb0, a0, b0, c0);
@@ -326,98 +342,175 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
         if (!live) continue;
         const size_t o = ((size_t)b * N + i) * N + j;
         row_planes(o, n_i, ca_i, cb_i, mi_n, mi_ca, mi_cb);
-        omega[o] = dihedral4_k3(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
-        theta[o] = dihedral4_k3(n_i, ca_i, cb_i, cb_j);
+        omega[o] = FAITHFUL ? dihedral4_ref(ca_i, cb_i, ca_j, cb_j) : dihedral4_k3(ca_i, cb_i, ca_j, cb_j);   // as coded at protstruc.py:811
+        theta[o] = FAITHFUL ? dihedral4_ref(n_i, ca_i, cb_i, cb_j) : dihedral4_k3(n_i, ca_i, cb_i, cb_j);
     }
 }
 
-// The same featuriser with NC (2 or 4) consecutive column residues per lane (N % NC == 0, planes aligned to 4 * NC bytes,
-// mask planes to NC bytes): every float plane is written with 4 * NC-byte stores and every mask plane with one NC-byte
-// store per row -- 1 / NC of the store instructions of the one-column kernel above (nine stores per pair there: three of
-// them single bytes).  A wave owns 64 * NC columns x its own rows: the four waves of a workgroup take different row pairs
-// of the chunk, so everything on the row side stays wave-uniform (scalar loads).  Same arithmetic per pair: same bits.
+// The featuriser on the skeleton of k3_sweep (round 4): one 1024-thread workgroup per CU, the row residues' N / CA / CB
+// points and their three mask bits staged once per segment in LDS (pair-interleaved), tasks of CH rows x 64 * NC columns
+// pulled from an LDS counter, NC = 2 or 4 consecutive column residues per lane -- every float plane goes out in 4 * NC-byte
+// stores and every mask plane in one NC-byte store per row, write-through -- and the two dihedrals' and the planar angle's
+// chains interleaved across the columns.  Same arithmetic per pair as k3_inter_residue_geometry above: same bits.
 template <bool EXACT, int NC>
-__global__ __launch_bounds__(256) void k3_inter_residue_geometry_cols(
+__global__ __launch_bounds__(1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int IR, int n_tiles, int n_chunks) {
+    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
-    typedef typename std::conditional<NC == 4, float4, float2>::type fvec;
     typedef typename std::conditional<NC == 4, uint32_t, uint16_t>::type mvec;
-    const unsigned w = blockIdx.x;
-    const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
-    const int b = (int)(rest / (unsigned)n_chunks);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int j0 = ((int)tile * 64 + lane) * NC;
-    const int i0 = (int)(rest % (unsigned)n_chunks) * IR, i1 = min(i0 + IR, N);   // IR and N even: whole row pairs
-    const bool live = j0 < N;                                                      // N % NC == 0: a lane's columns are in or out
-    const int jc = live ? j0 : N - NC;
-    f3 ca_j[NC], o_j[NC], cb_j[NC];
-    uint32_t mj_ca = 0x01010101u, mj_o = 0x01010101u, mj_cb = 0x01010101u;       // byte c = mask of column jc + c
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const float* sj = xyz + ((size_t)b * N + jc + c) * (size_t)A * 3;
-        ca_j[c] = load3(sj + 3); o_j[c] = load3(sj + 9); cb_j[c] = load3(sj + 12);
-    }
-    if (amask) {
-        mj_ca = mj_o = mj_cb = 0;
+    constexpr int POL = 16;                       // sc1: write-through
+    extern __shared__ f32x2 k3_rowbuf[];          // [row pair][N, CA, CB][xyz]; the mask words follow
+    __shared__ unsigned next_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int n_waves = (int)(blockDim.x >> 6);
+    const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
+    if (t0 >= t1) return;                         // whole workgroup
+    const int max_pairs = (N + 2) / 2;
+    uint32_t* rowmask = reinterpret_cast<uint32_t*>(k3_rowbuf + (size_t)max_pairs * 9);   // per row pair: byte 0 = row 2r, byte 1 = row 2r + 1; bits n = 1, ca = 2, cb = 4
+    int staged_b = -1, staged_lo = -1, staged_hi = -1;
+    for (unsigned g = t0 / (unsigned)n_chunks; g <= (t1 - 1u) / (unsigned)n_chunks; ++g) {   // g = b * n_strips + strip
+        const int c_lo = (int)(max(t0, g * (unsigned)n_chunks) - g * (unsigned)n_chunks);
+        const int c_hi = (int)(min(t1, (g + 1u) * (unsigned)n_chunks) - g * (unsigned)n_chunks);
+        const int b = (int)(g / (unsigned)n_strips), strip = (int)(g % (unsigned)n_strips);
+        const int r_lo = c_lo * CH, r_hi = min(c_hi * CH, N);
+        const float* xb = xyz + (size_t)b * N * (size_t)A * 3;   // uniform
+        const uint8_t* mb = amask ? amask + (size_t)b * N * A : nullptr;
+        __syncthreads();                                          // the previous segment's readers are done
+        if (b != staged_b || r_lo != staged_lo || r_hi != staged_hi) {
+            float* rb = reinterpret_cast<float*>(k3_rowbuf);
+            const int n_el = (r_hi - r_lo) * 9;
+            for (int e = (int)threadIdx.x; e < n_el; e += (int)blockDim.x) {
+                const int row = e / 9, rem = e - row * 9, q = rem / 3, c = rem - q * 3;
+                const int at = (q == 2) ? 4 : q;                  // N = 0, CA = 1, CB = 4
+                rb[((((row >> 1) * 3 + q) * 3 + c) << 1) + (row & 1)] = xb[(size_t)(r_lo + row) * (size_t)A * 3 + at * 3 + c];
+            }
+            const int n_pairs = (r_hi - r_lo + 1) / 2;
+            for (int r = (int)threadIdx.x; r < n_pairs; r += (int)blockDim.x) {
+                uint32_t w = 0x0707u;
+                if (mb) {
+                    const int ia = r_lo + 2 * r, ib = min(ia + 1, N - 1);
+                    const uint8_t* pa = mb + (size_t)ia * A;
+                    const uint8_t* pb = mb + (size_t)ib * A;
+                    w = (pa[0] != 0 ? 1u : 0u) | (pa[1] != 0 ? 2u : 0u) | (pa[4] != 0 ? 4u : 0u) |
+                        (pb[0] != 0 ? 0x100u : 0u) | (pb[1] != 0 ? 0x200u : 0u) | (pb[4] != 0 ? 0x400u : 0u);
+                }
+                rowmask[r] = w;
+            }
+            staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
+        }
+        if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
+        const int j0 = (strip * 64 + lane) * NC;
+        const bool live = j0 < N;                                 // N % NC == 0: a lane's columns are all in or all out
+        const int jc = live ? j0 : N - NC;
+        f3 ca_j[NC], o_j[NC], cb_j[NC];
+        uint32_t mj_ca = 0x01010101u, mj_o = 0x01010101u, mj_cb = 0x01010101u;   // byte c = mask of column jc + c
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const uint8_t* mj = amask + ((size_t)b * N + jc + c) * A;
-            mj_ca |= (mj[1] != 0 ? 1u : 0u) << (8 * c);
-            mj_o |= (mj[3] != 0 ? 1u : 0u) << (8 * c);
-            mj_cb |= (mj[4] != 0 ? 1u : 0u) << (8 * c);
+            const float* sj = xb + (size_t)(jc + c) * (size_t)A * 3;
+            ca_j[c] = load3(sj + 3); o_j[c] = load3(sj + 9); cb_j[c] = load3(sj + 12);
         }
-    }
-    for (int i = i0 + 2 * wave; i + 1 < i1; i += 8) {
-        const float* s0 = xyz + ((size_t)b * N + i) * (size_t)A * 3;   // wave-uniform
-        const float* s1 = s0 + (size_t)A * 3;
-        const f3v nv = mk3v(load3(s0), load3(s1)), cav = mk3v(load3(s0 + 3), load3(s1 + 3));
-        const f3v cbv = mk3v(load3(s0 + 12), load3(s1 + 12));
-        bool n0 = true, a0 = true, c0 = true, n1 = true, a1 = true, c1 = true;    // row masks of N, CA, CB (rows i, i + 1)
-        if (amask) {
-            const uint8_t* mi = amask + ((size_t)b * N + i) * A;
-            n0 = mi[0] != 0; a0 = mi[1] != 0; c0 = mi[4] != 0;
-            n1 = mi[A] != 0; a1 = mi[A + 1] != 0; c1 = mi[A + 4] != 0;
+        if (mb) {
+            mj_ca = mj_o = mj_cb = 0;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const uint8_t* mj = mb + (size_t)(jc + c) * A;
+                mj_ca |= (mj[1] != 0 ? 1u : 0u) << (8 * c);
+                mj_o |= (mj[3] != 0 ? 1u : 0u) << (8 * c);
+                mj_cb |= (mj[4] != 0 ? 1u : 0u) << (8 * c);
+            }
         }
-        if (!live) continue;
-        const size_t o = ((size_t)b * N + i) * N + j0;     // multiple of NC
-        auto put = [&](float* plane, const f32x2 (&v)[NC]) {
+        __syncthreads();
+        // per plane: the segment's rows as one buffer (uniform base, the lane's constant byte offset, the row's byte offset
+        // as a scalar)
+        const size_t seg = ((size_t)b * N + (size_t)r_lo) * N;
+        auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
+        const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
+                                     r_th = rs(theta + seg), r_ph = rs(phi + seg), r_mca = rs(m_ca + seg), r_mcb = rs(m_cb + seg),
+                                     r_mno = rs(m_no + seg);
+        const int lane_off = j0 * 4, lane_off_m = j0;
+        const int row_bytes = N * 4;
+        auto put = [&](const __amdgpu_buffer_rsrc_t& r, int so, const f32x2 (&v)[NC]) {
             if constexpr (NC == 4) {
-                *reinterpret_cast<float4*>(plane + o) = make_float4(v[0].x, v[1].x, v[2].x, v[3].x);
-                *reinterpret_cast<float4*>(plane + o + N) = make_float4(v[0].y, v[1].y, v[2].y, v[3].y);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), r, lane_off, so, POL);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), r, lane_off, so + row_bytes, POL);
             } else {
-                *reinterpret_cast<float2*>(plane + o) = make_float2(v[0].x, v[1].x);
-                *reinterpret_cast<float2*>(plane + o + N) = make_float2(v[0].y, v[1].y);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), r, lane_off, so, POL);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), r, lane_off, so + row_bytes, POL);
             }
         };
-        // plane by plane, so that only one plane's results are live at a time
-        f32x2 v[NC];
+        auto putm = [&](const __amdgpu_buffer_rsrc_t& r, int so, uint32_t w) {
+            if constexpr (NC == 4)
+                __builtin_amdgcn_raw_buffer_store_b32(w, r, lane_off_m, so, POL);
+            else
+                __builtin_amdgcn_raw_buffer_store_b16((mvec)w, r, lane_off_m, so, POL);
+        };
+        int c = c_lo + wave;
+        while (c < c_hi) {
+            const int i0 = (c - c_lo) * CH;                       // rows relative to r_lo (CH is even: pairs stay aligned)
+            const int i1 = min(i0 + CH, r_hi - r_lo);
+            for (int i = i0; i < i1; i += 2) {
+                const int r = i >> 1;
+                const bool two = i + 1 < i1;                      // the last row of an odd N has no partner (uniform)
+                const f3v nv = {k3_rowbuf[r * 9 + 0], k3_rowbuf[r * 9 + 1], k3_rowbuf[r * 9 + 2]};
+                const f3v cav = {k3_rowbuf[r * 9 + 3], k3_rowbuf[r * 9 + 4], k3_rowbuf[r * 9 + 5]};
+                const f3v cbv = {k3_rowbuf[r * 9 + 6], k3_rowbuf[r * 9 + 7], k3_rowbuf[r * 9 + 8]};
+                const uint32_t mw = rowmask[r];
+                const int so = i * row_bytes, som = i * N;
+                // plane by plane, so that only one plane's results are live at a time; each plane's results are pinned
+                // before its store (see k3_sweep)
+                auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[NC]) {
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(cav, mk3v(ca_j[c], ca_j[c]));
-        put(d_ca, v);
+                    for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
+                    if (live) {
+                        if (two) {
+                            put(rr, so, v);
+                        } else if constexpr (NC == 4) {
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rr, lane_off, so, POL);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rr, lane_off, so, POL);
+                        }
+                    }
+                };
+                f3v NV[NC], CAV[NC], CBV[NC], CAJ[NC], CBJ[NC];
+                f32x2 v[NC];
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(cbv, mk3v(cb_j[c], cb_j[c]));
-        put(d_cb, v);
+                for (int cc = 0; cc < NC; ++cc) {
+                    NV[cc] = nv; CAV[cc] = cav; CBV[cc] = cbv;
+                    CAJ[cc] = mk3v(ca_j[cc], ca_j[cc]); CBJ[cc] = mk3v(cb_j[cc], cb_j[cc]);
+                }
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = dist3v_t<EXACT>(nv, mk3v(o_j[c], o_j[c]));
-        put(d_no, v);
+                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cav, CAJ[cc]);
+                emit(r_dca, v);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = angle3v(cav, cbv, mk3v(cb_j[c], cb_j[c]));
-        put(phi, v);
+                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cbv, CBJ[cc]);
+                emit(r_dcb, v);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = dihedral4v_k3(cav, cbv, mk3v(ca_j[c], ca_j[c]), mk3v(cb_j[c], cb_j[c]));   // protstruc.py:811
-        put(omega, v);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) v[c] = dihedral4v_k3(nv, cav, cbv, mk3v(cb_j[c], cb_j[c]));
-        put(theta, v);
-        *reinterpret_cast<mvec*>(m_ca + o) = (mvec)(a0 ? mj_ca : 0u);
-        *reinterpret_cast<mvec*>(m_ca + o + N) = (mvec)(a1 ? mj_ca : 0u);
-        *reinterpret_cast<mvec*>(m_cb + o) = (mvec)(c0 ? mj_cb : 0u);
-        *reinterpret_cast<mvec*>(m_cb + o + N) = (mvec)(c1 ? mj_cb : 0u);
-        *reinterpret_cast<mvec*>(m_no + o) = (mvec)(n0 ? mj_o : 0u);
-        *reinterpret_cast<mvec*>(m_no + o + N) = (mvec)(n1 ? mj_o : 0u);
+                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
+                emit(r_dno, v);
+                angle3v_n<NC>(CAV, CBV, CBJ, v);
+                emit(r_ph, v);
+                dihedral4v_k3_n<NC>(CAV, CBV, CAJ, CBJ, v);         // as coded at protstruc.py:811
+                emit(r_om, v);
+                dihedral4v_k3_n<NC>(NV, CAV, CBV, CBJ, v);
+                emit(r_th, v);
+                if (live) {
+                    putm(r_mca, som, (mw & 2u) ? mj_ca : 0u);
+                    putm(r_mcb, som, (mw & 4u) ? mj_cb : 0u);
+                    putm(r_mno, som, (mw & 1u) ? mj_o : 0u);
+                    if (two) {
+                        putm(r_mca, som + N, (mw & 0x200u) ? mj_ca : 0u);
+                        putm(r_mcb, som + N, (mw & 0x400u) ? mj_cb : 0u);
+                        putm(r_mno, som + N, (mw & 0x100u) ? mj_o : 0u);
+                    }
+                }
+            }
+            unsigned nx = 0;
+            if (lane == 0) nx = atomicAdd(&next_task, 1u);
+            c = __builtin_amdgcn_readfirstlane((int)nx);
+        }
     }
 }
 
@@ -458,9 +551,17 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
 
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
-           int out_rows, int out_row_origin, hipStream_t s) {
+           int out_rows, int out_row_origin, bool faithful, hipStream_t s) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin;
+    if (faithful) {
+        const int IR = 16;
+        const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
+        const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel,
+                         row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+    }
     const uintptr_t al = reinterpret_cast<uintptr_t>(out);
     // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS
     const bool fits = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX;
@@ -481,16 +582,16 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    return ps_launch(k3_pairwise_angles<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel, row_begin,
-                     row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+    return ps_launch(k3_pairwise_angles<NP, SRC, false>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel,
+                     row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
 }
 
 template <int NP, int... SRCS>
 int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin,
-             int row_end, int out_rows, int out_row_origin, hipStream_t s) {
+             int row_end, int out_rows, int out_row_origin, bool faithful, hipStream_t s) {
     int rc = (int)hipErrorInvalidValue;
     (void)((srcmask == SRCS
-                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s), true)
+                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, faithful, s), true)
                 : false) ||
            ...);
     return rc;
@@ -500,8 +601,9 @@ int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, con
 
 extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N, int A, int n_points, const int* src,
                                       const int* atom, int row_begin, int row_end, int out_rows, int out_row_origin,
-                                      void* stream) {
+                                      int exact_angles, void* stream) {
     if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
+    if (exact_angles != 0 && exact_angles != 1) return (int)hipErrorInvalidValue;
     if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
@@ -516,50 +618,67 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n_points == 4)
         return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(
-            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, exact_angles != 0, s);
     return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
-                                               out_row_origin, s);
+                                               out_row_origin, exact_angles != 0, s);
 }
 
 extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb,
                                              float* d_no, float* omega, float* theta, float* phi, uint8_t* d_ca_mask,
                                              uint8_t* d_cb_mask, uint8_t* d_no_mask, int B, int N, int A,
-                                             int exact_sqrt, void* stream) {
+                                             int exact_sqrt, int exact_angles, void* stream) {
     if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
         return (int)hipErrorInvalidValue;
-    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1)) return (int)hipErrorInvalidValue;
+    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || (exact_angles != 0 && exact_angles != 1))
+        return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    {   // two columns per lane where every store is aligned: N even, 8-byte (masks: 2-byte) aligned planes
-        constexpr int NC = 2;
-        uintptr_t al = 0;
+    if (!exact_angles) {   // NC columns per lane where every store is aligned: N % NC == 0, 4 * NC-byte (masks: NC-byte) aligned planes
+        uintptr_t alf = 0, alm = 0;
         for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
                               (const void*)theta, (const void*)phi})
-            al |= reinterpret_cast<uintptr_t>(p) & (4u * NC - 1u);
+            alf |= reinterpret_cast<uintptr_t>(p);
         for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
-            al |= reinterpret_cast<uintptr_t>(p) & (NC - 1u);
-        if (N % NC == 0 && al == 0) {
-            const int IRq = 32;   // 4 waves x 4 trips of a row pair
-            const int n_tiles = (N + 64 * NC - 1) / (64 * NC), n_chunks = (N + IRq - 1) / IRq;
-            const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
-            if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-            if (exact_sqrt)
-                return ps_launch(k3_inter_residue_geometry_cols<true, NC>, dim3((unsigned)n_wg), dim3(256), 0,
-                                 reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
-                                 d_ca_mask, d_cb_mask, d_no_mask, N, A, IRq, n_tiles, n_chunks);
-            return ps_launch(k3_inter_residue_geometry_cols<false, NC>, dim3((unsigned)n_wg), dim3(256), 0,
-                             reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
-                             d_ca_mask, d_cb_mask, d_no_mask, N, A, IRq, n_tiles, n_chunks);
+            alm |= reinterpret_cast<uintptr_t>(p);
+        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4);     // one structure's rows: points + mask words
+        const bool fits = need <= K3_LDS_MAX;
+        const bool ok4 = fits && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0;
+        const bool ok2 = fits && N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0;
+        if (ok4 || ok2) {
+            const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
+            const int NC = (K3_FEATURISE_NC4 && ok4 && (!ok2 || w4 <= w2)) ? 4 : 2;
+            const int cus = k3_cu_count();
+            const int n_strips = (N + 64 * NC - 1) / (64 * NC);
+            const int CH = k3_rows_per_task((unsigned long long)n_strips * B, N, cus);
+            const int n_chunks = (N + CH - 1) / CH;
+            const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
+            if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+            const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + cus - 1) / cus, 4ull);
+            const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+            const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
+            auto go = [&](auto kernel, bool& prepared) -> int {
+                if (!__atomic_load_n(&prepared, __ATOMIC_ACQUIRE)) {   // > 64 KB of dynamic LDS: allowed once per kernel
+                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3_LDS_MAX);
+                    if (e != hipSuccess) return (int)e;
+                    __atomic_store_n(&prepared, true, __ATOMIC_RELEASE);
+                }
+                return ps_launch(kernel, dim3(grid), dim3(1024), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
+                                 d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
+                                 (unsigned)n_tasks, tasks_per_wg);
+            };
+            static bool prep[4] = {false, false, false, false};
+            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4>, prep[0]) : go(k3_featurise<false, 4>, prep[1]);
+            return exact_sqrt ? go(k3_featurise<true, 2>, prep[2]) : go(k3_featurise<false, 2>, prep[3]);
         }
     }
     const int IR = 16;
     const int n_tiles = (N + 255) / 256, n_chunks = (N + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    if (exact_sqrt)
-        return ps_launch(k3_inter_residue_geometry<true>, dim3((unsigned)n_wg), dim3(256), 0,
-                         reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
-                         d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
-    return ps_launch(k3_inter_residue_geometry<false>, dim3((unsigned)n_wg), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi,
-                     d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
+    auto go = [&](auto kernel) {
+        return ps_launch(kernel, dim3((unsigned)n_wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
+                         d_ca, d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
+    };
+    if (exact_angles) return exact_sqrt ? go(k3_inter_residue_geometry<true, true>) : go(k3_inter_residue_geometry<false, true>);
+    return exact_sqrt ? go(k3_inter_residue_geometry<true, false>) : go(k3_inter_residue_geometry<false, false>);
 }

@@ -173,6 +173,27 @@ __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
     return atan2_ps(y, x);
 }
 
+// ---- the FAITHFUL forms (round 4): geometry.dihedral / geometry.angle op for op in the reference's order ----
+// What `exact_angles` of ps_pairwise_angles_f32 / ps_inter_residue_geometry_f32 selects, as `exact_sqrt` does for K1: three
+// cross products, y divided by |b1| (correctly rounded square root, IEEE division), the device library's atan2f / acosf
+// (<= 2 ulp; the reference's np.arctan2 / torch.arccos are libm-grade as well) -- no algebraic rewriting, no reciprocal
+// square roots, no polynomials of this file.  About 2.5x the instructions of the fast forms.
+__device__ __forceinline__ float dihedral4_ref(f3 a, f3 b, f3 c, f3 d) {
+    const f3 b0 = sub3(a, b), b1 = sub3(c, b), b2 = sub3(d, c);
+    const f3 n1 = cross3(b0, b1);          // np.cross(b0, b1)
+    const f3 n2 = cross3(b2, b1);          // np.cross(b2, b1)
+    const f3 m = cross3(n1, n2);
+    const float x = dot3(n1, n2);
+    const float y = dot3(m, b1) / norm3(b1);
+    return atan2f(y, x);
+}
+
+__device__ __forceinline__ float angle3_ref(f3 a, f3 b, f3 c) {
+    const f3 ba = sub3(a, b), bc = sub3(c, b);
+    const float cosine = dot3(ba, bc) / (norm3(ba) * norm3(bc));
+    return acosf(cosine);                  // no clamp, as geometry.py:64-71
+}
+
 // atan2 of the PAIRWISE kernels (K3 and the fused featuriser; K2 and the pointwise entry keep atan2_ps with every IEEE
 // special case).  Same polynomial, same quadrant logic, same signed-zero behaviour (atan2(+0, +0) = +0, atan2(+0, -0) =
 // pi); what is dropped are six per-element compare / select instructions that only matter for infinite arguments:

@@ -249,6 +249,19 @@ def get_exact_sqrt(device=None) -> bool:
     return bool(_lib.get_tuning("k1_exact_sqrt", device))
 
 
+def set_exact_angles(flag: bool, device=None) -> None:
+    """K3 / featuriser arithmetic on ``device`` (default: the current one).  False (default): the fast forms -- exact
+    where the reference is exact, otherwise within the conditioning gates (3.8e-6 of off-diagonal dihedrals more than
+    1e-5 from the reference at unit scale).  True: geometry.dihedral / geometry.angle in the reference's order of
+    operations (three cross products, division by |b1|, library atan2 / acos): no entry beyond 1e-5 on well-conditioned
+    inputs, about 2.5x the time.  ``PROTSTRUC_AMD_EXACT_ANGLES=1`` makes True the default of every device."""
+    _lib.set_exact_angles(flag, device)
+
+
+def get_exact_angles(device=None) -> bool:
+    return bool(_lib.get_exact_angles(device))
+
+
 def autotune_pairwise_distance(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor], out_dist: torch.Tensor,
                                out_mask: torch.Tensor):
     """Time K1's launch configurations on the given buffers now and keep the fastest for this device (results are
@@ -413,7 +426,7 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
         if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
             rc = _lib.load().ps_pairwise_angles_f32(
                 _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
-                _stream(xyz))
+                _lib.get_exact_angles(xyz.device), _stream(xyz))
     _lib.check(rc, "ps_pairwise_angles_f32")
     return out
 
@@ -438,7 +451,8 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
             fp, kp, plane = f.data_ptr(), k.data_ptr(), B * N * N     # plane addresses by arithmetic, not by 9 views
             rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * plane * i for i in range(6)],
                                                            *[kp + plane * i for i in range(3)], B, N, A,
-                                                           _lib.get_tuning("k1_exact_sqrt", dev), _stream(xyz))
+                                                           _lib.get_tuning("k1_exact_sqrt", dev),
+                                                           _lib.get_exact_angles(dev), _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
     out = dict(zip(fkeys, f.unbind(0)))
     out.update(zip(mkeys, k.unbind(0)))

@@ -1202,6 +1202,68 @@ def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
             assert same(c, one[:, r0:r1]), (npts, si, sj)
 
 
+def test_k3_exact_angles_mode(SB):
+    """`ops.set_exact_angles(True)` (ABI 4: `exact_angles` of ps_pairwise_angles_f32 / ps_inter_residue_geometry_f32) selects
+    geometry.dihedral / geometry.angle in the reference's order of operations (geometry.py:110-124, :64-66), as
+    `exact_sqrt` does for K1.  At B=8, N=256, unit scale: NO off-diagonal dihedral more than 1e-5 from the oracle, max
+    <= 1e-6 (the fast default: 3.8e-6 of entries beyond 1e-5, max 6.5e-5); the planar angle within its conditioning
+    gate and closer to the oracle than the fast form; exact where the reference is exact; the featuriser's three angle
+    planes equal the K3 launches bit for bit in this mode too; the default comes back unchanged."""
+    from protstruc_amd import ops
+    B, N = 8, 256
+    g = torch.Generator().manual_seed(0)
+    xyz = torch.randn(B, N, 15, 3, generator=g)
+    sb = SB.from_xyz(xyz)
+    off = ~torch.eye(N, dtype=torch.bool).expand(B, N, N)
+    wrap = lambda d: torch.minimum(d.abs(), (2 * np.pi - d.abs()).abs())
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    assert ops.get_exact_angles() is False
+    fast = {}
+    for key, (ai, aj) in {"omega": (["CA", "CB"], ["CA", "CB"]), "theta": (["N", "CA", "CB"], ["CB"])}.items():
+        fast[key] = sb.pairwise_dihedrals(ai, aj)
+    fast["phi"] = sb.pairwise_planar_angles(["CA", "CB"], ["CB"])
+    try:
+        ops.set_exact_angles(True)
+        assert ops.get_exact_angles() is True
+        ex = {}
+        for key, (ai, aj, si, sj) in {"omega": (["CA", "CB"], ["CA", "CB"], [1, 4], [1, 4]),
+                                      "theta": (["N", "CA", "CB"], ["CB"], [0, 1, 4], [4])}.items():
+            ex[key] = sb.pairwise_dihedrals(ai, aj)
+            ref = O.pairwise_dihedrals(xyz, si, sj)
+            err = wrap(ex[key].cpu() - ref)[off]
+            assert err.max().item() <= 1e-6 and (err > 1e-5).sum().item() == 0, (key, err.max().item())
+            diag = torch.diagonal(ex[key], dim1=1, dim2=2)
+            assert ((diag == 0) & ~torch.signbit(diag)).all()             # exactly +0.0 where the reference is
+        ex["phi"] = sb.pairwise_planar_angles(["CA", "CB"], ["CB"])
+        ref = O.pairwise_planar_angles(xyz, [1, 4], [4])
+        both = off & ~(ref.isnan() | ex["phi"].cpu().isnan())
+        e_exact, e_fast = (ex["phi"].cpu() - ref).abs()[both], (fast["phi"].cpu() - ref).abs()[both & ~fast["phi"].cpu().isnan()]
+        assert (e_exact > 1e-5).float().mean().item() <= 1e-4
+        assert e_exact.median().item() <= e_fast.median().item() + 1e-9
+        assert torch.diagonal(ex["phi"], dim1=1, dim2=2).isnan().all()
+        geo = sb.inter_residue_geometry()
+        for key in ("omega", "theta", "phi"):
+            assert same(geo[key], ex[key]), key
+            assert not torch.equal(ex[key].nan_to_num(5.0), fast[key].nan_to_num(5.0))   # it IS another arithmetic
+        # odd N and a row range take the same path
+        x5 = xyz[:2, :37].contiguous().cuda()
+        full = ops.pairwise_angles(x5, [1, 4], [1, 4], 4)
+        part = ops.pairwise_angles(x5, [1, 4], [1, 4], 4, row_begin=5, row_end=20, compact=True)
+        assert same(part, full[:, 5:20])
+        assert wrap(full.cpu() - O.pairwise_dihedrals(xyz[:2, :37], [1, 4], [1, 4]))[~torch.eye(37, dtype=torch.bool).expand(2, 37, 37)].max() <= 1e-6
+    finally:
+        ops.set_exact_angles(False)
+    assert same(sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]), fast["omega"])
+    geo = sb.inter_residue_geometry()
+    assert same(geo["omega"], fast["omega"]) and same(geo["phi"], fast["phi"])
+    lib = __import__("protstruc_amd._lib", fromlist=["load"]).load()
+    import ctypes
+    arr = (ctypes.c_int * 4)
+    xg = xyz[:1].contiguous().cuda(); out = torch.empty(1, N, N, device="cuda")
+    rc = lib.ps_pairwise_angles_f32(xg.data_ptr(), out.data_ptr(), 1, N, 15, 4, arr(0, 0, 1, 1), arr(1, 4, 1, 4), 0, N, N, 0, 2, None)
+    assert rc == 1                                                        # exact_angles outside {0, 1}: refused before any launch
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)

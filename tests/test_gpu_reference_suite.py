@@ -280,3 +280,57 @@ def test_with_numpy(ps):                                                # :22
 def test_mixed(ps):                                                     # :32  (any tensor among the inputs -> tensor out)
     x = ps[1].dot(torch.tensor([1.0, 2.0, 3.0]), np.array([4.0, 5.0, 6.0]))
     assert isinstance(x, torch.Tensor) and float(x) == 32.0
+
+
+# ---------------------------------------------------------------- the entries the reference's own tests / notebooks parse
+# The reference's network tests fetch 1REX / 4EOT / 2ZIL from the RCSB and its tutorials ship 1REX, 4EOT, 4uuj under
+# docs/tutorials/; those files are fixtures here (tests/golden/), so the numbers the reference states are asserted as stated.
+REX = os.path.join(G, "1REX.pdb")
+REX_EOT = [REX, os.path.join(G, "4EOT.pdb")]
+
+
+def test_1REX_pairwise_distance_matrix_as_the_reference_states(ps):     # :122-137, pairwise_distance_matrix.ipynb cells 3-5
+    SB, _, ATOM = ps
+    sb = SB.from_pdb(REX)
+    dist, dist_mask = sb.pairwise_distance_matrix()
+    assert dist.shape == (1, 130, 130, 15, 15) and dist_mask.shape == (1, 130, 130, 15, 15)
+    ca_dist, cb_dist = dist[:, :, :, ATOM.CA, ATOM.CA], dist[:, :, :, ATOM.CB, ATOM.CB]
+    assert (ca_dist >= 0).all() and (cb_dist[~torch.isnan(cb_dist)] >= 0).all()
+    assert (ca_dist == dist[:, :, :, 1, 1]).all()
+    two = SB.from_pdb(REX_EOT)
+    d2, m2 = two.pairwise_distance_matrix()
+    assert d2.shape == (2, 184, 184, 15, 15) and m2.shape == (2, 184, 184, 15, 15)
+    assert two.get_total_lengths().tolist() == [130, 184]              # :157-163, notebook cell 5
+    # the padded structure's block equals the single-structure result bit for bit (same kernel arithmetic)
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(0), b.nan_to_num(0))
+    assert same(d2[0, :130, :130], dist[0]) and torch.equal(m2[0, :130, :130], dist_mask[0])
+
+
+def test_1REX_frames_as_the_reference_states(ps):                       # :140-154
+    sb = ps[0].from_pdb(REX)
+    assert sb.backbone_orientations("N", "CA", "C").shape == (1, 130, 3, 3)
+    for atom in ["N", "CA", "C"]:
+        assert sb.backbone_translations(atom).shape == (1, 130, 3)
+    assert sb.pairwise_dihedrals(atoms_i=["C"], atoms_j=["N", "CA", "C"]).shape == (1, 130, 130)      # :166-176
+    assert sb.pairwise_dihedrals(atoms_i=["N", "CA", "C"], atoms_j=["N"]).shape == (1, 130, 130)
+    assert (sb.get_n_terminal_mask().sum(axis=1) == 1).all() and (sb.get_c_terminal_mask().sum(axis=1) == 1).all()   # :98-119 (single chain)
+
+
+def test_ramachandran_counts_of_the_tutorial(ps):
+    """docs/tutorials/ramachandran_plot.ipynb cells 3-8: dihedrals (2, 184, 3); 128 / 180 residues with a valid (phi, psi)
+    pair -- the reference's count and biotite's own."""
+    sb = ps[0].from_pdb(REX_EOT)
+    assert sb.get_xyz().shape == (2, 184, 15, 3)
+    dihedrals, dihedral_mask = sb.backbone_dihedrals()
+    assert dihedrals.shape == (2, 184, 3)
+    valid = dihedral_mask[:, :, [0, 1]].all(-1)
+    assert valid.sum(1).tolist() == [128, 180]
+    assert not torch.isnan(dihedrals[:, :, :2][valid]).any()
+
+
+def test_4uuj_residue_count_of_the_tutorial(ps):                        # k_nearest_residues.ipynb cells 4-10
+    sb = ps[0].from_pdb(os.path.join(G, "4uuj.pdb"))
+    assert sb.get_xyz().shape == (1, 545, 15, 3)
+    ca = sb.get_xyz()[0, :, 1]
+    query = ca[~torch.isnan(ca).any(-1)][:12]
+    assert sb.get_topk_nearest_residue_mask(query_xyz=query, k=128)[0].shape == (545,)

@@ -397,7 +397,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < f.np; ++k) sel.atom[k] = f.atom[k];
         printf("---- %s\n", f.name);
         CK(hipMemset(ref, 0xFF, ob));
-        T t0 = time_it([&] { ps_pairwise_angles_f32(xyz, ref, B, N, A, f.np, f.src, f.atom, 0, N, N, 0, nullptr); }, reps);
+        T t0 = time_it([&] { ps_pairwise_angles_f32(xyz, ref, B, N, A, f.np, f.src, f.atom, 0, N, N, 0, 0, nullptr); }, reps);
         printf("%-34s %8.1f / %8.1f / %8.1f\n", "base (product)", t0.mean_us, t0.min_us, t0.lo_us);
         CK(hipMemcpy(hr.data(), ref, ob, hipMemcpyDeviceToHost));
         auto run = [&](const char* name, const std::function<int()>& fn) {
@@ -498,7 +498,7 @@ int main(int argc, char** argv) {
         run("cu NC=" #NCv " pol=" #POLv " CH=" #CHv " thr=" #THR " wg/cu=" #WPC " rounds=" #RND, [&] { return launch_cu<NPv, SRCv, NCv, POLv>(xyz, out, B, N, A, sel, CHv, nullptr, THR, WPC, RND); })
 #define SWEEP(NPv, SRCv) \
         CU(NPv, SRCv, 4, 16, 8, 1024, 1, 1); CU(NPv, SRCv, 4, 16, 4, 1024, 1, 1); CU(NPv, SRCv, 4, 16, 16, 1024, 1, 1); CU(NPv, SRCv, 2, 16, 8, 1024, 1, 1); \
-        run("product again", [&] { return ps_pairwise_angles_f32(xyz, out, B, N, A, f.np, f.src, f.atom, 0, N, N, 0, nullptr); })
+        run("product again", [&] { return ps_pairwise_angles_f32(xyz, out, B, N, A, f.np, f.src, f.atom, 0, N, N, 0, 0, nullptr); })
         if (f.np == 4 && f.src[2] == 1) { SWEEP(4, 12); }
         else if (f.np == 4) { SWEEP(4, 8); }
         else { SWEEP(3, 4); }
