@@ -201,6 +201,15 @@ def check_outputs(xyz, mask, out_d, out_m, n_blocks=64, seed=7):
     return fails
 
 
+def all_ranks_early(dist, world, obj):
+    """``obj`` of every rank (object collective on the control group; a no-op list at world 1 without a group)."""
+    if dist is None or not dist.is_initialized():
+        return [obj]
+    got = [None] * world
+    dist.all_gather_object(got, obj)
+    return got
+
+
 def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, steps=2, group=None):
     """BASELINE config 4: residue-sharded K1 into a full-size buffer + all-gather (native RCCL and torch paths),
     each part timed with HIP events on the launch stream; max over ranks.  Every verdict (an exception in a step, a
@@ -214,6 +223,16 @@ def rowshard_allgather(dev, rank, world, max_over_ranks, backend, shared_gpu, st
     b, n = (C4_B, C4_N) if not shared_gpu else (2, C4_N // 2)
     xyz, mask = synth(1234, b, n)  # same seed on every rank: inputs are replicated, only outputs are sharded
     xyz, mask = xyz.to(dev), mask.to(dev)
+    # pre-flight: every rank holds the FULL matrix (the all-gather destination), 151 GB at config 4, plus RCCL's own
+    # buffers.  A rank that cannot must say so as a clean error on every rank, not die in an OOM traceback while its
+    # peers wait in a collective.
+    need = b * n * n * BYTES_PER_PAIR + (2 << 30)
+    free, total = torch.cuda.mem_get_info(dev)
+    short = [s_ for s_ in all_ranks_early(dist, world, None if free >= need else
+                                          f"rank {rank} ({dev}): {free / 1e9:.1f} GB free of {total / 1e9:.1f}, "
+                                          f"the full matrix + workspace needs {need / 1e9:.1f} GB") if s_]
+    if short:
+        raise RuntimeError("not enough device memory for the row-sharded matrix: " + "; ".join(short))
     out_d = torch.empty(b, n, n, N_ATOM, N_ATOM, device=dev)
     out_m = torch.empty(b, n, n, N_ATOM, N_ATOM, dtype=torch.bool, device=dev)
     lo, hi = D.shard_rows(n, rank, world)
@@ -304,29 +323,49 @@ def launch_ranks(n, argv):
     with socket.socket() as sock:          # a free rendezvous port
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool supports only dmabuf IPC; with the legacy mode RCCL's
+    # (and torch's) cross-process buffer sharing fails at hipIpcGetMemHandle ("invalid argument") as soon as two ranks
+    # map each other's memory.  The pool exports 0 already; an inherited value is kept, an unset one becomes 0.
     base = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(n),
                 HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, os.path.abspath(__file__)] + argv
-    procs = []
+    procs, last_err, out0_chunks, relays = [], [b""] * n, [], []
+
+    def relay_stderr(r, pipe):              # pass a child's stderr through, remembering its last non-empty line
+        for raw in iter(pipe.readline, b""):
+            sys.stderr.buffer.write(raw)
+            sys.stderr.buffer.flush()
+            if raw.strip():
+                last_err[r] = raw.strip()
+        pipe.close()
+
+    def collect_stdout(pipe):
+        for raw in iter(lambda: pipe.read(65536), b""):
+            out0_chunks.append(raw)
+        pipe.close()
+
     for r in range(n):
         env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), stderr=subprocess.PIPE)
+        procs.append(p)
+        relays.append(threading.Thread(target=relay_stderr, args=(r, p.stderr), daemon=True))
+        if r == 0:
+            relays.append(threading.Thread(target=collect_stdout, args=(p.stdout,), daemon=True))
+    for t in relays:
+        t.start()
     deadline = time.time() + float(os.environ.get("PS_BENCH_LAUNCH_TIMEOUT", "570"))   # inside the driver's 600 s
-    out0, codes, timed_out = b"", [], False
+    codes, timed_out = [], False
     for r, p in enumerate(procs):
         try:
-            if r == 0:
-                out0, _ = p.communicate(timeout=max(1.0, deadline - time.time()))
-            else:
-                p.wait(timeout=max(1.0, deadline - time.time()))
+            p.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
             timed_out = True
             p.kill()                        # exactly the child we started
-            if r == 0:
-                out0, _ = p.communicate()
-            else:
-                p.wait()
+            p.wait()
         codes.append(p.returncode)
+    for t in relays:
+        t.join(timeout=5.0)
+    out0 = b"".join(out0_chunks)
     line = None
     for cand in out0.decode(errors="replace").splitlines():
         cand = cand.strip()
@@ -334,8 +373,14 @@ def launch_ranks(n, argv):
             line = cand
     if line is not None:
         print(line, flush=True)
-    else:
-        print(f"bench.py launcher: rank 0 printed no result line (exit codes {codes})", file=sys.stderr, flush=True)
+    if line is None or any(codes):
+        # say which rank failed how: exit code and the last thing it wrote to stderr
+        print(f"bench.py launcher: {'rank 0 printed no result line; ' if line is None else ''}exit codes {codes}"
+              f"{' (timed out)' if timed_out else ''}", file=sys.stderr, flush=True)
+        for r, c in enumerate(codes):
+            if c != 0 or line is None:
+                print(f"bench.py launcher:   rank {r}: exit code {c}; last stderr line: "
+                      f"{last_err[r].decode(errors='replace')[:400] or '(none)'}", file=sys.stderr, flush=True)
     worst = max((c if c >= 0 else 128 - c) for c in codes)
     if timed_out:
         worst = max(worst, 3)
@@ -496,6 +541,33 @@ def main():
             os._exit(5)
         check = "ok"
 
+    # ---- what the library DEFAULT launch configuration does on the same buffers (the timed launches above ran the explicit
+    # tuner's pick; StructureBatch.pairwise_distance_matrix() without a tuner call launches candidate 0).  Timed like the
+    # headline -- mean of `steps` launches, one HIP-event pair each -- after the timed region and the check. ----
+    default_cfg = dict(ops._K1_CANDIDATE_PATTERN[0])
+    tuned_cfg = {f: _lib.get_tuning("k1_" + f, dev) for f in default_cfg}
+    default_kernel_ms = kernel_ms
+    if tuned_cfg != default_cfg:
+        try:
+            for f, v in default_cfg.items():
+                _lib.set_tuning("k1_" + f, v, dev)
+            for _ in range(max(1, args.warmup)):
+                step()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * args.steps)]
+            for e in ev:
+                e.record()
+            torch.cuda.synchronize(dev)
+            for k in range(args.steps):
+                ev[2 * k].record()
+                step()
+                ev[2 * k + 1].record()
+            torch.cuda.synchronize(dev)
+            default_kernel_ms = sum(ev[2 * k].elapsed_time(ev[2 * k + 1]) for k in range(args.steps)) / args.steps
+        finally:
+            for f, v in tuned_cfg.items():
+                _lib.set_tuning("k1_" + f, v, dev)
+    default_kernel_ms = max_over_ranks([default_kernel_ms])[0]
+
     # ---- which class of allocation did this run draw?  fill rate of the very buffers that were timed (they have been
     # checked; their contents are no longer needed) ----
     fill_GBps = fill_rate_GBps(out_d, out_m)
@@ -541,6 +613,12 @@ def main():
                      "buffer_fill_what": "torch.fill_ on the two timed output buffers, HIP events, mean of 5 after one "
                                          "warm-up, measured after the timed region and the check"},
         "pct_hbm_roofline": 100.0 * achieved / HBM_PEAK_GBPS,
+        # the timed launches ran `config.k1_autotune`'s pick; these three say what the library default does on the same buffers
+        "default_config": ops._cand_label(default_cfg) + (" (= the tuner's pick: the headline IS the default launch)"
+                                                           if tuned_cfg == default_cfg else ""),
+        "default_config_kernel_ms": default_kernel_ms,
+        "default_config_frac_of_hbm_peak": B * N_RES * N_RES * BYTES_PER_PAIR / (default_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "tuner_gain": default_kernel_ms / kernel_ms_max,
     }
     if dist:
         result["rccl_ranks"] = world if args.backend == "nccl" else 0
@@ -559,6 +637,18 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_stdout_fd, 1)
             print(json.dumps(result), flush=True)
+
+    if world == 1:
+        # The headline is complete and checked.  What follows at N = 1 is informational (allocation lottery: 4 x 18.9 GB of
+        # allocations and ~60 launches; the CPU baseline: ~20 s of host work): a hang or a hard fault in it must not lose the
+        # result line -- the watchdog prints it and ends the process with a non-zero code, like the N > 1 path below.
+        def watchdog_n1():
+            time.sleep(900)
+            result["informational_sections_error"] = "timed out after 900 s (allocation lottery / cpu_baseline)"
+            emit()
+            os._exit(3)
+
+        threading.Thread(target=watchdog_n1, daemon=True).start()
 
     if world == 1 and not args.no_lottery and shop_report is None:
         # Informational, AFTER the measurement above and not part of it: the same kernel timed on four fresh output

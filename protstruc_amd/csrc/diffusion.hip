@@ -124,29 +124,34 @@ __global__ __launch_bounds__(256) void k5_diffuse(float* __restrict__ xyz, const
         off = rng_state[1];
     }
     const unsigned blk_begin = blockIdx.x * 1024u;
-    const BetaSpan sp = beta_span_fill(beta, blk_begin, min(1024u, n_total - blk_begin), nps, n_struct, keep_add);
-    __syncthreads();
     const unsigned g = blockIdx.x * 256u + threadIdx.x;
     const unsigned e0 = g * 4u;
-    if (e0 < n_total) {
-        float eps[4], x[4];
-        const bool full = e0 + 4u <= n_total;
-        if (noise) {
-            if (full) {
-                float4 t = *reinterpret_cast<const float4*>(noise + e0);
-                eps[0] = t.x; eps[1] = t.y; eps[2] = t.z; eps[3] = t.w;
-            } else {
-                for (int k = 0; k < 4; ++k) eps[k] = (e0 + k < n_total) ? noise[e0 + k] : 0.f;
-            }
-        } else {
-            normal4(seed, off, g, eps);
-        }
+    const bool live = e0 < n_total, full = e0 + 4u <= n_total;
+    // The coordinates (and the injected noise) are requested FIRST: they depend on nothing but the lane's index, so their
+    // memory latency overlaps the beta loads, the square roots and the barrier of beta_span_fill and the Philox rounds
+    // instead of following them (round 4: a wave of this kernel spent 69 % of its life in s_waitcnt, two dependent
+    // memory latencies one after the other -- profiles/r04_diag_k5_pmc_waves.json).
+    float eps[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
         if (full) {
-            float4 t = *reinterpret_cast<const float4*>(xyz + e0);
+            const float4 t = *reinterpret_cast<const float4*>(xyz + e0);
             x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
         } else {
             for (int k = 0; k < 4; ++k) x[k] = (e0 + k < n_total) ? xyz[e0 + k] : 0.f;
         }
+        if (noise) {
+            if (full) {
+                const float4 t = *reinterpret_cast<const float4*>(noise + e0);
+                eps[0] = t.x; eps[1] = t.y; eps[2] = t.z; eps[3] = t.w;
+            } else {
+                for (int k = 0; k < 4; ++k) eps[k] = (e0 + k < n_total) ? noise[e0 + k] : 0.f;
+            }
+        }
+    }
+    const BetaSpan sp = beta_span_fill(beta, blk_begin, min(1024u, n_total - blk_begin), nps, n_struct, keep_add);
+    if (live && !noise) normal4(seed, off, g, eps);
+    __syncthreads();
+    if (live) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float2 ka = beta_of(sp, beta, min(e0 + k, n_total - 1u), keep_add);

@@ -565,8 +565,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_a15_pat(const float* __restri
 //     bookkeeping at all;
 //   * [pbeg, pend) need not be 16-pair aligned (odd N; one structure of a row-sharded launch): partially active
 //     groups take the element-wise path and inactive pairs are never written.
-// FLOG2: log2(pairs per chunk).  7 (128 pairs = 144 KB of output per chunk) is the product default; 4..6 are the
-// small-granule variants of round 3's bounded A/B (cfg.flat_fl_log2; profiles/r03_k1_ab_small_granule.log).
+// FLOG2: log2(pairs per chunk).  The launcher's default is 6 (64 pairs = 72 KB + 18 KB of output per chunk); 7 (128
+// pairs) and the small granules 4..5 of round 3's bounded A/B are cfg.flat_fl_log2 (profiles/r03_k1_ab_small_granule.log).
 constexpr int FR = 16;   // row residues staged per chunk (N >= 16 -> a chunk of up to 128 pairs touches at most 9 rows)
 
 // floor(x / d) for x, d < 2^23 with rcp = 1.0f / d
@@ -1438,9 +1438,18 @@ inline void plan_append(char* dst, size_t cap, const char* text) {
     dst[n] = 0;
 }
 
+// LDS of a launch: the dynamic request, and what the kernel declares statically (only the flat families declare any)
+struct K1Lds {
+    size_t dynamic;
+    unsigned static_bytes;
+    K1Lds(size_t d, unsigned st = 0) : dynamic(d), static_bytes(st) {}
+    K1Lds(int d) : dynamic((size_t)d), static_bytes(0) {}
+};
+
 template <typename... KArgs, typename... Args>
 inline int k1_go(const K1Go& go, const char* family, const char* name, int tparam, void (*kernel)(KArgs...), dim3 grid,
-                 dim3 block, size_t lds, Args&&... args) {
+                 dim3 block, K1Lds lds_spec, Args&&... args) {
+    const size_t lds = lds_spec.dynamic;
     if (!go.plan) return ps_launch(kernel, grid, block, lds, go.s, static_cast<Args&&>(args)...);
     ps_k1_plan& pl = *go.plan;
     char full[64];
@@ -1448,9 +1457,9 @@ inline int k1_go(const K1Go& go, const char* family, const char* name, int tpara
     else snprintf(full, sizeof full, "%s", name);
     plan_append(pl.kernel, sizeof pl.kernel, full);
     plan_append(pl.family, sizeof pl.family, family);
-    hipFuncAttributes fa;
-    unsigned static_lds = 0;
-    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(kernel)) == hipSuccess) static_lds = (unsigned)fa.sharedSizeBytes;
+    // static LDS from the kernel's own declarations (compile-time constants at the call site): the plan query makes NO HIP
+    // call -- it neither initialises the runtime in the calling process nor depends on a device being present
+    const unsigned static_lds = lds_spec.static_bytes;
     const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
     if (pl.n_launches == 0) {
         pl.n_workgroups = (unsigned)(n_wg > 0xFFFFFFFFull ? 0xFFFFFFFFull : n_wg);
@@ -1539,7 +1548,8 @@ int launch_a15_flat(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
     const size_t pad = (size_t)g.flat_lds_pad_kb * 1024;  // idle dynamic LDS: residency cap
 #define PS_K1_FLAT2(EX_, HM_, L_)                                                                                 \
-    k1_go(go, "flat", "k1_pairdist_a15_flat", 1 << L_, k1_pairdist_a15_flat<EX_, HM_, L_>, dim3(n_wg), dim3(256), pad, \
+    k1_go(go, "flat", "k1_pairdist_a15_flat", 1 << L_, k1_pairdist_a15_flat<EX_, HM_, L_>, dim3(n_wg), dim3(256),     \
+          K1Lds(pad, (unsigned)((((1 << L_) + FR) * RS) * sizeof(float4) + (2 * (1 << L_) + FR) * sizeof(uint32_t))),    \
           xyz, amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr,       \
           (int)cpw, remap, rn, rr)
 #define PS_K1_FLAT(EX_, HM_)                                                                                      \
@@ -1670,7 +1680,9 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const double rn = 1.0 / (double)N, rr = 1.0 / (double)out_rows;
 #define PS_K1_FLATA(EX_, HM_)                                                                                     \
-    k1_go(go, "flatA", "k1_pairdist_flatA", A, k1_pairdist_flatA<A, EX_, HM_>, dim3(n_wg), dim3(256), 0, xyz,     \
+    k1_go(go, "flatA", "k1_pairdist_flatA", A, k1_pairdist_flatA<A, EX_, HM_>, dim3(n_wg), dim3(256),             \
+          K1Lds(0, (unsigned)((FlatA<A>::FLn + FlatA<A>::FRn) * FlatA<A>::RS * sizeof(float4) +                      \
+                              (2 * FlatA<A>::FLn + FlatA<A>::FRn) * sizeof(typename FlatA<A>::mask_t))), xyz,       \
           amask, dist, dmask, B, N, out_rows, out_row_origin, pbeg, pend, n_ranges, range_stride, cpr, (int)cpw,  \
           remap, rn, rr)
     if (g.exact_sqrt) return amask ? PS_K1_FLATA(true, true) : PS_K1_FLATA(true, false);
@@ -1703,8 +1715,9 @@ extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
     cfg->struct_size = (int)sizeof(ps_k1_config);
     cfg->flat = 1;
     cfg->rows_per_block = 1;
-    // 8 KB of idle LDS per workgroup of the pattern kernel (resident workgroups per CU 4 -> 3): with 1 row per workgroup
-    // the fastest configuration on every output buffer measured, fast or slow (profiles/r02_k1_ab_buffers.log)
+    // 20 KB of idle LDS per workgroup of the pattern kernel: with its 32-residue tiles (jt = 0 -> 32) five workgroups are
+    // resident per CU; never more than 2 % behind the best configuration on the output buffers of ten boxes
+    // (profiles/r03_k1_ab_lean_*.log; the 8 KB + 128-residue tiles of rounds 2-3 are a tuner candidate)
     cfg->lds_pad_kb = 20;
     cfg->flat_cpw = 1;
     cfg->xcd_remap = 1;

@@ -22,37 +22,48 @@ def pytest_configure(config):
 # those have ended, so that at most five processes use the card at any time -- ``python3 bench.py --gpus 2 --backend
 # gloo ...`` exactly as the driver invokes the bench for N > 1.  A process that has initialised the GPU must not start
 # other programs on this pool, so the orchestrator is started HERE, at session start, before this pytest process has
-# touched the GPU (torch.cuda.device_count() does not initialise it); the tests wait for the verdict files.
+# touched the GPU (torch.cuda.device_count() does not initialise it) -- in pytest_collection_finish, once the selected
+# items are known; the tests wait for the verdict files.
 REHEARSALS = {}
 _ORCHESTRATOR = None
 
 
-def pytest_sessionstart(session):
-    global _ORCHESTRATOR
+_WHY_NOT_STARTED = "pytest_collection_finish has not run"
+
+
+def pytest_collection_finish(session):
+    """Start the rehearsal children if (and only if) a test that waits for them was SELECTED -- decided from the collected
+    items, after -m / -k / file arguments have been applied, not guessed from the command line.  Collection imports the
+    test modules but does not touch the GPU (no test module calls torch.cuda at import time), so this is still early
+    enough for the rule above."""
+    global _ORCHESTRATOR, _WHY_NOT_STARTED
     import subprocess
     import tempfile
 
-    markexpr = (session.config.option.markexpr or "").strip()
-    if "not gpu" in markexpr or os.environ.get("PS_NO_REHEARSAL"):
+    if _ORCHESTRATOR is not None:
         return
-    # A run that cannot select a rehearsal test (a -k expression without negation that names none of them, or explicit
-    # test files other than theirs) does not pay for the child processes.
-    tokens = ("multirank", "rehears", "bench_gpus", "c_abi", "c99", "consumer", "rank", "gloo", "rccl", "rowshard", "world")
-    kw = (session.config.option.keyword or "").strip().lower()
-    if kw and "not " not in kw and not any(t in kw for t in tokens):
+    if os.environ.get("PS_NO_REHEARSAL"):
+        _WHY_NOT_STARTED = "PS_NO_REHEARSAL is set"
         return
-    files = [a for a in session.config.args if a.endswith(".py") or ".py::" in a]
-    if files and not any(("multirank" in f or "c_abi" in f) for f in files):
+    wanted = [it for it in session.items
+              if os.path.basename(str(it.fspath)) in ("test_gpu_multirank.py", "test_c_abi_from_c.py")]
+    if not wanted:
+        _WHY_NOT_STARTED = "no selected test waits for a rehearsal"
         return
     try:
         if torch.cuda.device_count() < 1:
+            _WHY_NOT_STARTED = "torch.cuda.device_count() == 0 (no GPU visible)"
             return
-    except Exception:  # noqa: BLE001
+    except Exception as exc:  # noqa: BLE001
+        _WHY_NOT_STARTED = f"torch.cuda.device_count() raised {type(exc).__name__}: {exc}"
         return
     outdir = tempfile.mkdtemp(prefix="ps_rehearse_")
     script = os.path.join(ROOT, "tools", "gpu_session_rehearsals.py")
     log = open(os.path.join(outdir, "orchestrator.log"), "w")
-    _ORCHESTRATOR = subprocess.Popen([sys.executable, script, "--outdir", outdir], stdout=log, stderr=subprocess.STDOUT)
+    # its own session / process group: pytest_sessionfinish can end the orchestrator AND everything it started (the
+    # rehearsal launchers and their ranks) by signalling that group -- exactly the processes this session created
+    _ORCHESTRATOR = subprocess.Popen([sys.executable, script, "--outdir", outdir], stdout=log, stderr=subprocess.STDOUT,
+                                     start_new_session=True)
     for name in ("gloo_world2", "rccl_world1", "c_abi_demo", "bench_gpus2"):
         REHEARSALS[name] = {"exit": os.path.join(outdir, name + ".exit"), "out": os.path.join(outdir, name + ".json"),
                             "log": os.path.join(outdir, name + ".log"), "stdout": os.path.join(outdir, name + ".stdout")}
@@ -63,7 +74,7 @@ def wait_rehearsal(name, timeout):
     import time
 
     if name not in REHEARSALS:
-        pytest.fail("the rehearsals were not started (conftest.pytest_sessionstart found no GPU?)")
+        pytest.fail(f"the rehearsals were not started: {_WHY_NOT_STARTED}")
     r = REHEARSALS[name]
     t_end = time.time() + timeout
     while not os.path.exists(r["exit"]):
@@ -78,8 +89,32 @@ def wait_rehearsal(name, timeout):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    if _ORCHESTRATOR is not None and _ORCHESTRATOR.poll() is None:
-        _ORCHESTRATOR.terminate()      # exactly the process we started (its children end with their own timeouts)
+    """End whatever the orchestrator still runs (a failed or interrupted session leaves its children behind otherwise,
+    on the GPU, until their own 300-570 s timeouts): signal the process GROUP the orchestrator leads -- it was started
+    with start_new_session=True, so the group is exactly the orchestrator, the rehearsal launchers and their ranks."""
+    import signal
+    import time
+
+    if _ORCHESTRATOR is None:
+        return
+    try:
+        pgid = os.getpgid(_ORCHESTRATOR.pid)
+    except ProcessLookupError:
+        return
+    if pgid == os.getpgid(0):          # never our own group (cannot happen with start_new_session=True)
+        return
+    for sig, wait in ((signal.SIGTERM, 3.0), (signal.SIGKILL, 0.0)):
+        try:
+            os.killpg(pgid, sig)
+        except ProcessLookupError:
+            break
+        t_end = time.time() + wait
+        while time.time() < t_end and _ORCHESTRATOR.poll() is None:
+            time.sleep(0.1)
+    try:
+        _ORCHESTRATOR.wait(timeout=5)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def load_golden(name):

@@ -1264,6 +1264,44 @@ def test_k3_exact_angles_mode(SB):
     assert rc == 1                                                        # exact_angles outside {0, 1}: refused before any launch
 
 
+def test_k3_planar_angle_collinear_and_extreme_arms(SB):
+    """Where the fast planar angle (cos = dot * rsq(|ba|^2 |bc|^2), polynomial acos) may leave the reference, pinned:
+    exactly collinear points (the reference's correctly rounded division gives cos = -1 or 1 exactly -> pi or 0; one ulp of
+    v_rsq_f32 puts the fast cosine at 1 -+ 6e-8 -> within 4e-4 of it or NaN), arms of 1e10 (the product of the squared
+    lengths overflows: rsq(inf) = 0 -> pi / 2) and of 1e-12 (it underflows: NaN).  Documented in INTEGRATION.md; the
+    faithful mode (`set_exact_angles(True)`) has none of the three and equals the oracle to 1e-6."""
+    from protstruc_amd import ops
+    A = 5
+    xyz = torch.zeros(1, 4, A, 3)
+    # residue r: CA = slot 1, CB = slot 4.  planar(CA_i, CB_i, CB_j) with i = 0
+    xyz[0, 0, 1] = torch.tensor([0.0, 0.0, 0.0]); xyz[0, 0, 4] = torch.tensor([3.0, 0.0, 0.0])     # arm (-3, 0, 0)
+    xyz[0, 1, 4] = torch.tensor([6.0, 0.0, 0.0])          # collinear, opposite side: angle pi
+    xyz[0, 2, 4] = torch.tensor([1.0, 0.0, 0.0])          # collinear, same side: angle 0
+    xyz[0, 3, 4] = torch.tensor([3.0, 7.0, 0.0])          # right angle
+    sb = SB.from_xyz(xyz)
+    ref = O.pairwise_planar_angles(xyz, [1, 4], [4])[0, 0]
+    assert ref[1].item() == pytest.approx(np.pi, abs=1e-6) and ref[2].item() == 0.0 and ref[3].item() == pytest.approx(np.pi / 2, abs=1e-6)
+    fast = sb.pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
+    for j in (1, 2):                                       # ill-conditioned: sqrt(2 ulp) ~ 3.5e-4, or NaN just past 1
+        assert fast[j].isnan() or abs(fast[j].item() - ref[j].item()) <= 5e-4
+    assert abs(fast[3].item() - np.pi / 2) <= 1e-6
+    big = xyz.clone(); big[0, :, :, :] *= 1e10
+    tiny = xyz.clone(); tiny[0, :, :, :] *= 1e-12
+    fb = SB.from_xyz(big).pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
+    ft = SB.from_xyz(tiny).pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
+    assert abs(fb[3].item() - np.pi / 2) <= 1e-6 and (fb[1].item() == pytest.approx(np.pi / 2, abs=1e-6) or fb[1].isnan())   # overflow: documented
+    assert ft[1].isnan() or abs(ft[1].item() - np.pi) <= 5e-4                                                          # underflow: documented
+    try:
+        ops.set_exact_angles(True)
+        for x in (xyz, big, tiny):
+            got = SB.from_xyz(x).pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
+            want = O.pairwise_planar_angles(x, [1, 4], [4])[0, 0]
+            assert torch.equal(got.isnan(), want.isnan())
+            assert (got - want).nan_to_num(0).abs().max().item() <= 1e-6
+    finally:
+        ops.set_exact_angles(False)
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)

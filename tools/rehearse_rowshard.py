@@ -145,6 +145,8 @@ def main():
     with socket.socket() as s:          # a free rendezvous port
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # dmabuf IPC only on this pool's host driver: with the legacy IPC mode cross-process buffer sharing (RCCL, torch) fails
+    # at hipIpcGetMemHandle; the pool exports 0, an unset variable becomes 0
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, os.path.abspath(__file__), "--world", str(args.world), "--backend", args.backend,
            "--out", args.out, "--port", str(port)] + (["--quick"] if args.quick else [])
