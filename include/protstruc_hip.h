@@ -54,11 +54,22 @@ const char* ps_error_string(int code);
  * Every setting produces the same bits (the two square-root modes differ by at most 1 ulp); the knobs only move
  * work between kernels and change the granule a workgroup writes.  Not part of the drop-in surface; no reference
  * counterpart.
+ *
+ * Two kinds of fields (the layout is one flat struct for ABI stability):
+ *   PRODUCTION -- what a caller or the explicit tuner (ops.autotune_pairwise_distance) sets:
+ *       exact_sqrt; rows_per_block, lds_pad_kb, jt (pattern kernel granule and residency); flat_cpw, flat_lds_pad_kb,
+ *       flat_fl_log2 = 0 / 6 / 7 (flat kernel granule); xcd_remap.
+ *   DIAGNOSTIC -- kept only so that closed A/B comparisons and the cross-check tests stay reproducible; no caller needs
+ *   them and the defaults (0) are the product:
+ *       variant = 1 (the simple kernels everywhere: the cross-check of the parity tests), flat = 0 / 2 / 4 and
+ *       rowphase = 1 / 2 (force or forbid a kernel family), store_nt = 1 (non-temporal stores: slower),
+ *       flat_fl_log2 = 4 / 5 (the small granules of round 3's bounded A/B), experiment (must be 0: refused by the
+ *       product library).
  */
 typedef struct ps_k1_config {
     int struct_size;      /* = sizeof(ps_k1_config); a launcher refuses any other value (caller built against another header) */
     int exact_sqrt;       /* 0: hardware v_sqrt_f32 (exact for 85 % of inputs, 1 ulp off otherwise); 1: correctly rounded */
-    int variant;          /* 0: fast kernels (pattern / flat pattern / row-tile / row-phase / fixed-A flat); 1: the simple
+    int variant;          /* [diagnostic] 0: fast kernels (pattern / flat pattern / row-tile / row-phase / fixed-A flat); 1: the simple
                              kernels everywhere (slot-decode kernel for A = 15, element-per-lane kernel otherwise) */
     int flat;             /* 0: none of the fast kernels for A != 15 and no flat kernel for A = 15; 1 (default): every kernel
                              where it is the fast path; 2: force the A = 15 flat pattern kernel; 4: force the fixed-A flat
@@ -73,12 +84,12 @@ typedef struct ps_k1_config {
     int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32; 128 for a launch
                              that writes the mask plane only) */
     int xcd_remap;        /* 1 (default): each XCD sweeps one contiguous eighth of the output; 0: natural grid order */
-    int store_nt;         /* 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
+    int store_nt;         /* [diagnostic] 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
-    int rowphase;         /* row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
+    int rowphase;         /* [diagnostic] row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
                              dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel; 1 also for A = 14, 15, 16,
                              24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead) */
-    int experiment;       /* must be 0 in the product library; timing experiments exist only in builds made with
+    int experiment;       /* [diagnostic] must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
                              run that writes WRONG values, +16 = fully unrolled group loop */
 } ps_k1_config;
