@@ -46,7 +46,7 @@ inline int k3_cu_count() {
     return n;
 }
 
-constexpr bool K3_FEATURISE_NC4 = false;          // four columns per lane spill ~70 registers in the featuriser: not used
+constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-thread workgroups (two waves per SIMD, 256 VGPRs each)
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
 
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
 // stores and every mask plane in one NC-byte store per row, write-through -- and the two dihedrals' and the planar angle's
 // chains interleaved across the columns.  Same arithmetic per pair as k3_inter_residue_geometry above: same bits.
 template <bool EXACT, int NC>
-__global__ __launch_bounds__(1024) void k3_featurise(
+__global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
@@ -662,7 +662,8 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                     if (e != hipSuccess) return (int)e;
                     __atomic_store_n(&prepared, true, __ATOMIC_RELEASE);
                 }
-                return ps_launch(kernel, dim3(grid), dim3(1024), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
+                // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves
+                return ps_launch(kernel, dim3(grid), dim3(NC == 4 ? 512 : 1024), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
                                  d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
                                  (unsigned)n_tasks, tasks_per_wg);
             };

@@ -3,7 +3,7 @@
 set -o pipefail
 O=gpurun_out/r02g
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 timeout -k 10 200 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; echo "bench rc=$?"
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o b -- python3 bench.py --no-cpu-baseline > $O/bench_traced.json 2> $O/bench_traced.err; echo "trace rc=$?"
 python3 tools/summarize_rocprof.py stats $O/trace $O/bench_kernel_stats.csv

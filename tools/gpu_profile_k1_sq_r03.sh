@@ -3,7 +3,7 @@
 set -o pipefail
 O=gpurun_out/${1:-k1sq}
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 timeout -k 10 240 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES -d $O/pmc -o b -- python3 bench.py --no-cpu-baseline --no-lottery --steps 3 > $O/bench.json 2> $O/bench.err; echo "pmc rc=$?"
 python3 tools/summarize_rocprof.py pmc $O/pmc $O/k1_sq_pmc.json 0
 rm -rf $O/pmc

@@ -1,6 +1,6 @@
 set -o pipefail
 mkdir -p gpurun_out/r02d
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 # K3: kernel trace, then SQ counters (separate passes)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r02d/k3_trace -o k3 -- python3 tools/profile_workload.py k3 10 > gpurun_out/r02d/k3_trace.log 2>&1; echo "k3 trace rc=$?"
 timeout -k 10 200 rocprofv3 --output-format csv --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d gpurun_out/r02d/k3_pmc -o k3 -- python3 tools/profile_workload.py k3 5 > gpurun_out/r02d/k3_pmc.log 2>&1; echo "k3 pmc rc=$?"
