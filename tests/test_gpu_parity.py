@@ -1302,6 +1302,31 @@ def test_k3_planar_angle_collinear_and_extreme_arms(SB):
         ops.set_exact_angles(False)
 
 
+def test_k3_inside_a_captured_graph(SB):
+    """The sweep kernels ask for more than 64 KB of dynamic LDS, which has to be allowed once per kernel
+    (hipFuncSetAttribute at an instantiation's first launch, possibly a captured one: legal during capture --
+    tools/microbench/capture_attr_test.hip, profiles/r04_capture_attr_test.log).  Captured launches of K3 must replay to
+    the eager result bit for bit."""
+    from protstruc_amd import ops
+    xyz, mask = synth(4242, 2, 64)
+    xg = xyz.cuda()
+    si, sj = [3, 0], [2, 1]                      # O_i, N_i | C_j, CA_j
+    si2, sj2 = [3], [0, 2, 1]                    # planar O_i | N_j, C_j
+    out = torch.empty(2, 64, 64, device="cuda")
+    out2 = torch.empty(2, 64, 64, device="cuda")
+    side = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            ops.pairwise_angles(xg, si, sj, 4, out=out)
+            ops.pairwise_angles(xg, si2, sj2, 3, out=out2)
+    out.fill_(7.0); out2.fill_(7.0)
+    g.replay()
+    torch.cuda.synchronize()
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    assert same(out, ops.pairwise_angles(xg, si, sj, 4)) and same(out2, ops.pairwise_angles(xg, si2, sj2, 3))
+
+
 def test_k3_errors(SB):
     xyz, mask = synth(5, 1, 8)
     sb = SB.from_xyz(xyz, mask)
