@@ -1302,6 +1302,27 @@ def test_k3_planar_angle_collinear_and_extreme_arms(SB):
         ops.set_exact_angles(False)
 
 
+@pytest.mark.parametrize("N", [2048, 4608])
+def test_k3_sweep_kernels_long_chains(SB, N):
+    """Long chains: one structure's rows fill 49-110 KB of the workgroup's LDS (N = 2048, 4608 with two row-side points), a
+    split with three row-side points no longer fits at N = 4608 and falls back to the one-column kernel, and a workgroup's
+    share of the task list is a fraction of one (structure, strip) segment.  Same bits as the one-column kernel."""
+    from protstruc_amd import ops
+    B = 1
+    xyz, _ = synth(1000 + N, B, N)
+    xg = xyz.cuda()
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    for npts, si, sj in [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (3, [1, 4], [4])]:
+        big = torch.full((B * N * N + 1,), 7.0, device="cuda")
+        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned -> one column per lane
+        fast = ops.pairwise_angles(xg, si, sj, npts)
+        assert same(fast, one), (npts, si, sj)
+        part = ops.pairwise_angles(xg, si, sj, npts, row_begin=N // 3, row_end=N // 3 + 777, compact=True)   # a shard
+        assert same(part, one[:, N // 3:N // 3 + 777])
+    geo = SB.from_xyz(xyz).inter_residue_geometry()
+    assert same(geo["omega"], ops.pairwise_angles(xg, [1, 4], [1, 4], 4)) and same(geo["phi"], ops.pairwise_angles(xg, [1, 4], [4], 3))
+
+
 def test_k3_inside_a_captured_graph(SB):
     """The sweep kernels ask for more than 64 KB of dynamic LDS, which has to be allowed once per kernel
     (hipFuncSetAttribute at an instantiation's first launch, possibly a captured one: legal during capture --
