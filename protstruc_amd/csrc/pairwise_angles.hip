@@ -46,6 +46,21 @@ inline int k3_cu_count() {
     return n;
 }
 
+// More than 64 KB of dynamic LDS has to be allowed once per kernel AND per device (function attributes belong to the module
+// a device loaded).  `done` is the kernel instantiation's own table; idempotent, so a race between two threads is harmless.
+template <typename K>
+inline int k3_allow_big_lds(K kernel, unsigned long long (&done)[1]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    const unsigned long long bit = 1ull << dev;
+    if (__atomic_load_n(&done[0], __ATOMIC_ACQUIRE) & bit) return 0;
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)(160 * 1024 - 256));
+    if (e != hipSuccess) return (int)e;
+    __atomic_fetch_or(&done[0], bit, __ATOMIC_RELEASE);
+    return 0;
+}
+
 constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-thread workgroups (two waves per SIMD, 256 VGPRs each)
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
@@ -538,13 +553,8 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
     const size_t need = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8;   // one segment's rows, pair-interleaved
     const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
-    static bool prepared = false;   // more than 64 KB of dynamic LDS has to be allowed once per kernel (idempotent)
-    if (!__atomic_load_n(&prepared, __ATOMIC_ACQUIRE)) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k3_sweep<NP, SRC, NC>),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3_LDS_MAX);
-        if (e != hipSuccess) return (int)e;
-        __atomic_store_n(&prepared, true, __ATOMIC_RELEASE);
-    }
+    static unsigned long long prepared[1] = {0};   // bit d: device d allows this kernel its dynamic LDS
+    if (const int e = k3_allow_big_lds(k3_sweep<NP, SRC, NC>, prepared)) return e;
     return ps_launch(k3_sweep<NP, SRC, NC>, dim3(grid), dim3(1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
                      out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
 }
@@ -655,19 +665,14 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + cus - 1) / cus, 4ull);
             const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
             const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
-            auto go = [&](auto kernel, bool& prepared) -> int {
-                if (!__atomic_load_n(&prepared, __ATOMIC_ACQUIRE)) {   // > 64 KB of dynamic LDS: allowed once per kernel
-                    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)K3_LDS_MAX);
-                    if (e != hipSuccess) return (int)e;
-                    __atomic_store_n(&prepared, true, __ATOMIC_RELEASE);
-                }
+            auto go = [&](auto kernel, unsigned long long (&prepared)[1]) -> int {
+                if (const int e = k3_allow_big_lds(kernel, prepared)) return e;
                 // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves
                 return ps_launch(kernel, dim3(grid), dim3(NC == 4 ? 512 : 1024), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
                                  d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
                                  (unsigned)n_tasks, tasks_per_wg);
             };
-            static bool prep[4] = {false, false, false, false};
+            static unsigned long long prep[4][1] = {{0}, {0}, {0}, {0}};
             if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4>, prep[0]) : go(k3_featurise<false, 4>, prep[1]);
             return exact_sqrt ? go(k3_featurise<true, 2>, prep[2]) : go(k3_featurise<false, 2>, prep[3]);
         }

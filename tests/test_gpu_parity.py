@@ -1323,6 +1323,43 @@ def test_k3_sweep_kernels_long_chains(SB, N):
     assert same(geo["omega"], ops.pairwise_angles(xg, [1, 4], [1, 4], 4)) and same(geo["phi"], ops.pairwise_angles(xg, [1, 4], [4], 3))
 
 
+def test_k3_differential_fuzz(SB):
+    """Random shapes, point splits, row ranges and output forms: the sweep kernels (and whatever the dispatcher picks for
+    the shape -- four or two columns per lane, the one-column kernel for odd N) against the one-column kernel reached
+    through a misaligned buffer, bit for bit; nothing outside the requested rows is written."""
+    from protstruc_amd import ops
+    rng = np.random.default_rng(20260404)
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    for trial in range(80):
+        B = int(rng.integers(1, 5))
+        N = int(rng.choice([int(rng.integers(1, 40)), int(rng.integers(40, 700)), 4 * int(rng.integers(1, 160)), 256, 384]))
+        A = int(rng.choice([5, 15, 25]))
+        npts = int(rng.choice([3, 4]))
+        n_i = int(rng.integers(0, npts + 1))
+        slots = [int(x) for x in rng.integers(0, A, size=npts)]
+        si, sj = slots[:n_i], slots[n_i:]
+        g = torch.Generator().manual_seed(7000 + trial)
+        xyz = torch.randn(B, N, A, 3, generator=g)
+        if trial % 5 == 0 and N > 2:
+            xyz[0, int(rng.integers(0, N))] = float("nan")
+        if trial % 7 == 0 and N > 2:
+            xyz[-1, 1] = xyz[-1, 0]
+        xg = xyz.cuda()
+        big = torch.full((B * N * N + 1,), 7.0, device="cuda")
+        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))
+        r0 = int(rng.integers(0, N)); r1 = int(rng.integers(r0, N + 1))
+        if trial % 3 == 0:
+            r0, r1 = 0, N
+        if trial % 2 == 0:
+            got = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True)
+            assert same(got, one[:, r0:r1]), (trial, B, N, A, npts, si, sj, r0, r1)
+        else:
+            buf = torch.full((B, N, N), 321.0, device="cuda")
+            ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
+            assert same(buf[:, r0:r1], one[:, r0:r1]), (trial, B, N, A, npts, si, sj, r0, r1)
+            assert (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+
+
 def test_k3_inside_a_captured_graph(SB):
     """The sweep kernels ask for more than 64 KB of dynamic LDS, which has to be allowed once per kernel
     (hipFuncSetAttribute at an instantiation's first launch, possibly a captured one: legal during capture --
