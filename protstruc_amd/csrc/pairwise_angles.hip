@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));   // points taken from the row residue
     constexpr int NPIq = NPI > 0 ? NPI : 1;
     constexpr int POL = 16;                       // sc1: write-through
-    extern __shared__ f32x2 k3_rowbuf[];          // [row pair][row point][xyz] of the current segment
+    extern __shared__ __attribute__((aligned(16))) f32x2 k3_rowbuf[];   // [row pair][row point][xyz] of the current segment
     __shared__ unsigned next_task;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -367,16 +367,17 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
 // pulled from an LDS counter, NC = 2 or 4 consecutive column residues per lane -- every float plane goes out in 4 * NC-byte
 // stores and every mask plane in one NC-byte store per row, write-through -- and the two dihedrals' and the planar angle's
 // chains interleaved across the columns.  Same arithmetic per pair as k3_inter_residue_geometry above: same bits.
-template <bool EXACT, int NC>
+template <bool EXACT, int NC, bool M16>
 __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
     int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
+    static_assert(!M16 || NC == 4, "16-byte mask stores ride on the four-column kernel");
     typedef typename std::conditional<NC == 4, uint32_t, uint16_t>::type mvec;
     constexpr int POL = 16;                       // sc1: write-through
-    extern __shared__ f32x2 k3_rowbuf[];          // [row pair][N, CA, CB][xyz]; the mask words follow
+    extern __shared__ __attribute__((aligned(16))) f32x2 k3_rowbuf[];   // [row pair][N, CA, CB][xyz]; the row mask words follow, then (M16) the strip's column mask bytes
     __shared__ unsigned next_task;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -385,6 +386,10 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     if (t0 >= t1) return;                         // whole workgroup
     const int max_pairs = (N + 2) / 2;
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(k3_rowbuf + (size_t)max_pairs * 9);   // per row pair: byte 0 = row 2r, byte 1 = row 2r + 1; bits n = 1, ca = 2, cb = 4
+    // M16: the mask planes get their OWN lane map -- a lane owns 16 consecutive column residues of one row, a store
+    // instruction carries four rows x 256 bytes (1 KB instead of the 256 B of the dword form: the mask planes are bound by
+    // the rate of store instructions, not by bytes).  colmask[plane][column of the strip], planes CA, CB, O.
+    uint8_t* colmask = reinterpret_cast<uint8_t*>(k3_rowbuf) + (((size_t)max_pairs * (9 * 8 + 4) + 15) & ~(size_t)15);   // 16-byte aligned
     int staged_b = -1, staged_lo = -1, staged_hi = -1;
     for (unsigned g = t0 / (unsigned)n_chunks; g <= (t1 - 1u) / (unsigned)n_chunks; ++g) {   // g = b * n_strips + strip
         const int c_lo = (int)(max(t0, g * (unsigned)n_chunks) - g * (unsigned)n_chunks);
@@ -437,7 +442,29 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                 mj_cb |= (mj[4] != 0 ? 1u : 0u) << (8 * c);
             }
         }
+        if constexpr (M16) {
+            for (int t = (int)threadIdx.x; t < 64 * NC; t += (int)blockDim.x) {
+                const int j = strip * 64 * NC + t;
+                uint8_t a = 0, c2 = 0, o = 0;
+                if (j < N) {
+                    a = c2 = o = 1;
+                    if (mb) {
+                        const uint8_t* mj = mb + (size_t)j * A;
+                        a = mj[1] != 0; c2 = mj[4] != 0; o = mj[3] != 0;
+                    }
+                }
+                colmask[t] = a; colmask[64 * NC + t] = c2; colmask[2 * 64 * NC + t] = o;
+            }
+        }
         __syncthreads();
+        k3_u32x4 cm_ca = {0, 0, 0, 0}, cm_cb = {0, 0, 0, 0}, cm_o = {0, 0, 0, 0};
+        const int gq = lane & 15, rq = lane >> 4;                 // M16: this lane's 16-column group and row of a 4-row store
+        const bool glive = strip * 64 * NC + 16 * gq < N;         // N % 16 == 0: a group is in or out
+        if constexpr (M16) {
+            cm_ca = *reinterpret_cast<const k3_u32x4*>(colmask + 16 * gq);
+            cm_cb = *reinterpret_cast<const k3_u32x4*>(colmask + 64 * NC + 16 * gq);
+            cm_o = *reinterpret_cast<const k3_u32x4*>(colmask + 2 * 64 * NC + 16 * gq);
+        }
         // per plane: the segment's rows as one buffer (uniform base, the lane's constant byte offset, the row's byte offset
         // as a scalar)
         const size_t seg = ((size_t)b * N + (size_t)r_lo) * N;
@@ -466,6 +493,19 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
         while (c < c_hi) {
             const int i0 = (c - c_lo) * CH;                       // rows relative to r_lo (CH is even: pairs stay aligned)
             const int i1 = min(i0 + CH, r_hi - r_lo);
+            if constexpr (M16) {                                  // the task's mask planes: four rows per store instruction
+                for (int k4 = i0; k4 < i1; k4 += 4) {
+                    const int rr = k4 + rq;
+                    if (rr < i1 && glive) {
+                        const uint32_t w = rowmask[rr >> 1] >> (8 * (rr & 1));
+                        const int vo = rr * N + strip * 64 * NC + 16 * gq;
+                        const k3_u32x4 z = {0, 0, 0, 0};
+                        __builtin_amdgcn_raw_buffer_store_b128((w & 2u) ? cm_ca : z, r_mca, vo, 0, POL);
+                        __builtin_amdgcn_raw_buffer_store_b128((w & 4u) ? cm_cb : z, r_mcb, vo, 0, POL);
+                        __builtin_amdgcn_raw_buffer_store_b128((w & 1u) ? cm_o : z, r_mno, vo, 0, POL);
+                    }
+                }
+            }
             for (int i = i0; i < i1; i += 2) {
                 const int r = i >> 1;
                 const bool two = i + 1 < i1;                      // the last row of an odd N has no partner (uniform)
@@ -511,7 +551,7 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                 emit(r_om, v);
                 dihedral4v_k3_n<NC>(NV, CAV, CBV, CBJ, v);
                 emit(r_th, v);
-                if (live) {
+                if (!M16 && live) {
                     putm(r_mca, som, (mw & 2u) ? mj_ca : 0u);
                     putm(r_mcb, som, (mw & 4u) ? mj_cb : 0u);
                     putm(r_mno, som, (mw & 1u) ? mj_o : 0u);
@@ -649,7 +689,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             alf |= reinterpret_cast<uintptr_t>(p);
         for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
             alm |= reinterpret_cast<uintptr_t>(p);
-        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4);     // one structure's rows: points + mask words
+        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 16 + 3 * 256;   // one structure's rows: points + mask words; the strip's column mask bytes
         const bool fits = need <= K3_LDS_MAX;
         const bool ok4 = fits && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0;
         const bool ok2 = fits && N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0;
@@ -672,9 +712,11 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                                  d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
                                  (unsigned)n_tasks, tasks_per_wg);
             };
-            static unsigned long long prep[4][1] = {{0}, {0}, {0}, {0}};
-            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4>, prep[0]) : go(k3_featurise<false, 4>, prep[1]);
-            return exact_sqrt ? go(k3_featurise<true, 2>, prep[2]) : go(k3_featurise<false, 2>, prep[3]);
+            static unsigned long long prep[6][1] = {{0}, {0}, {0}, {0}, {0}, {0}};
+            const bool m16 = NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // 16-byte mask stores: whole 16-column groups, aligned planes
+            if (m16) return exact_sqrt ? go(k3_featurise<true, 4, true>, prep[4]) : go(k3_featurise<false, 4, true>, prep[5]);
+            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4, false>, prep[0]) : go(k3_featurise<false, 4, false>, prep[1]);
+            return exact_sqrt ? go(k3_featurise<true, 2, false>, prep[2]) : go(k3_featurise<false, 2, false>, prep[3]);
         }
     }
     const int IR = 16;

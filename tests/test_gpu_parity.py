@@ -1651,8 +1651,11 @@ def test_inter_residue_geometry_golden(SB):
             assert_close(v, g[k], bad_frac=1.0 / g[k].numel())
 
 
-@pytest.mark.parametrize("N", [100, 101, 258, 34])   # even lengths: two columns per lane (one / three column tiles, a
-def test_inter_residue_geometry_matches_unfused_kernels(SB, N):   # partly idle wave); odd: the one-column kernel
+# 100, 258, 34: two columns per lane (one / three strips, a partly idle wave); 101: odd, the one-column kernel; 256, 512: four
+# columns per lane with 16-byte mask stores; 208: the same with a partial last strip (13 of 16 column groups live); 200: four
+# columns per lane, N % 16 != 0 -> dword mask stores
+@pytest.mark.parametrize("N", [100, 101, 258, 34, 256, 200, 208, 512])
+def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     """The fused featuriser must equal the K1 slices -- in BOTH square-root modes of the device (it takes the mode K1
     takes: the hardware square root by default, the correctly rounded one after set_exact_sqrt(True)), the two modes
     within 1 ulp of each other -- and the K3 calls it replaces, bit for bit."""
