@@ -113,7 +113,66 @@ __device__ __forceinline__ void rng_advance_by_last_block(uint64_t* rng_state, u
     }
 }
 
-// K5: one lane per group of four consecutive coordinates; a workgroup covers 1024 coordinates
+// The same bookkeeping with the ticket taken EARLY (round 4).  rng_advance_by_last_block takes its ticket at the very end of a
+// workgroup, and the workgroup cannot retire before the returning atomic has come back (1-3 us with every CU issuing one):
+// at config 5's shape that was 3 of K5's 11.5 us -- the injected-noise form, which reads 50 % more bytes but takes no ticket,
+// ran 8.2 us (profiles/r04_k5_trace_stats.csv).  A ticket only has to follow the workgroup's READ of the offset, so:
+// thread 0 alone reads (seed, offset) from memory, hands them to the other waves through LDS (they pick them up after the
+// barrier the kernels have anyway) and takes the ticket at once -- the atomic's operand is made to depend on the loaded offset,
+// so it cannot be performed before the read has returned -- and looks at the ticket's value only at the end, after the stores.
+struct RngTicket {
+    unsigned long long sub_ticket;
+};
+
+__device__ __forceinline__ RngTicket rng_read_and_take_ticket(uint64_t* rng_state, uint64_t (&rng_sh)[2]) {
+    RngTicket t{0ull};
+    if (threadIdx.x == 0) {
+        const uint64_t seed = rng_state[0], off = rng_state[1];
+        rng_sh[0] = seed;
+        rng_sh[1] = off;
+        unsigned zero;
+        asm volatile("v_and_b32 %0, 0, %1" : "=v"(zero) : "v"((unsigned)off));   // 0, but only once `off` has arrived
+        const unsigned r = blockIdx.x & 31u;
+        unsigned long long* sub = reinterpret_cast<unsigned long long*>(rng_state + 16 + 16 * r);
+        t.sub_ticket = atomicAdd(sub, 1ull + (unsigned long long)zero);
+    }
+    return t;
+}
+
+// The ticket alone, for kernels whose waves read (seed, offset) themselves and have USED them before a workgroup barrier:
+// called by every thread right after that barrier, thread 0 takes the ticket.
+__device__ __forceinline__ RngTicket rng_take_ticket(uint64_t* rng_state) {
+    RngTicket t{0ull};
+    if (threadIdx.x == 0) {
+        const unsigned r = blockIdx.x & 31u;
+        t.sub_ticket = atomicAdd(reinterpret_cast<unsigned long long*>(rng_state + 16 + 16 * r), 1ull);
+    }
+    return t;
+}
+
+__device__ __forceinline__ void rng_finish(uint64_t* rng_state, uint64_t new_off, RngTicket t) {
+    if (threadIdx.x == 0) {
+        const unsigned r = blockIdx.x & 31u;
+        const unsigned long long members = (gridDim.x - r + 31u) >> 5;  // workgroups with blockIdx % 32 == r
+        if (t.sub_ticket == members - 1ull) {                            // every one of them has read the offset
+            unsigned long long* sub = reinterpret_cast<unsigned long long*>(rng_state + 16 + 16 * r);
+            *sub = 0;
+            const unsigned long long groups = gridDim.x < 32u ? gridDim.x : 32u;
+            unsigned long long* top = reinterpret_cast<unsigned long long*>(rng_state + 2);
+            if (atomicAdd(top, 1ull) == groups - 1ull) {
+                *top = 0;
+                rng_state[1] = new_off;
+            }
+        }
+    }
+}
+
+// K5: a lane owns GPL = 2 groups of four consecutive coordinates, 1024 coordinates apart (a workgroup covers 2048): both
+// loads are requested up front, and the grid is half the waves -- one round of the chip at config 5's shape instead of 2.1
+// (round 4).  Group g draws from Philox counter g whatever the lane layout, so the noise stream is the one the fused and the
+// trajectory kernels draw.
+constexpr int K5_GPL = 2;
+
 __global__ __launch_bounds__(256) void k5_diffuse(float* __restrict__ xyz, const float* __restrict__ beta,
                                                   unsigned n_total, unsigned nps, unsigned n_struct,
                                                   uint64_t* __restrict__ rng_state, const float* __restrict__ noise) {
@@ -123,49 +182,69 @@ __global__ __launch_bounds__(256) void k5_diffuse(float* __restrict__ xyz, const
         seed = rng_state[0];
         off = rng_state[1];
     }
-    const unsigned blk_begin = blockIdx.x * 1024u;
-    const unsigned g = blockIdx.x * 256u + threadIdx.x;
-    const unsigned e0 = g * 4u;
-    const bool live = e0 < n_total, full = e0 + 4u <= n_total;
+    const unsigned blk_begin = blockIdx.x * (1024u * K5_GPL);
     // The coordinates (and the injected noise) are requested FIRST: they depend on nothing but the lane's index, so their
-    // memory latency overlaps the beta loads, the square roots and the barrier of beta_span_fill and the Philox rounds
-    // instead of following them (round 4: a wave of this kernel spent 69 % of its life in s_waitcnt, two dependent
-    // memory latencies one after the other -- profiles/r04_diag_k5_pmc_waves.json).
-    float eps[4] = {0.f, 0.f, 0.f, 0.f}, x[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-        if (full) {
-            const float4 t = *reinterpret_cast<const float4*>(xyz + e0);
-            x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-        } else {
-            for (int k = 0; k < 4; ++k) x[k] = (e0 + k < n_total) ? xyz[e0 + k] : 0.f;
-        }
-        if (noise) {
-            if (full) {
-                const float4 t = *reinterpret_cast<const float4*>(noise + e0);
-                eps[0] = t.x; eps[1] = t.y; eps[2] = t.z; eps[3] = t.w;
+    // memory latency overlaps the beta loads, the square roots and the barrier of beta_span_fill and the Philox rounds.
+    unsigned g[K5_GPL], e0[K5_GPL];
+    bool live[K5_GPL], full[K5_GPL];
+    float eps[K5_GPL][4], x[K5_GPL][4];
+#pragma unroll
+    for (int u = 0; u < K5_GPL; ++u) {
+        g[u] = blockIdx.x * (256u * K5_GPL) + 256u * u + threadIdx.x;
+        e0[u] = g[u] * 4u;
+        live[u] = e0[u] < n_total;
+        full[u] = e0[u] + 4u <= n_total;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) eps[u][k] = x[u][k] = 0.f;
+        if (live[u]) {
+            if (full[u]) {
+                const float4 t = *reinterpret_cast<const float4*>(xyz + e0[u]);
+                x[u][0] = t.x; x[u][1] = t.y; x[u][2] = t.z; x[u][3] = t.w;
             } else {
-                for (int k = 0; k < 4; ++k) eps[k] = (e0 + k < n_total) ? noise[e0 + k] : 0.f;
+                for (int k = 0; k < 4; ++k) x[u][k] = (e0[u] + k < n_total) ? xyz[e0[u] + k] : 0.f;
+            }
+            if (noise) {
+                if (full[u]) {
+                    const float4 t = *reinterpret_cast<const float4*>(noise + e0[u]);
+                    eps[u][0] = t.x; eps[u][1] = t.y; eps[u][2] = t.z; eps[u][3] = t.w;
+                } else {
+                    for (int k = 0; k < 4; ++k) eps[u][k] = (e0[u] + k < n_total) ? noise[e0[u] + k] : 0.f;
+                }
             }
         }
     }
-    const BetaSpan sp = beta_span_fill(beta, blk_begin, min(1024u, n_total - blk_begin), nps, n_struct, keep_add);
-    if (live && !noise) normal4(seed, off, g, eps);
+    const BetaSpan sp = beta_span_fill(beta, blk_begin, min(1024u * K5_GPL, n_total - blk_begin), nps, n_struct, keep_add);
+    // the Philox rounds (the vector unit's quarter-rate 32 x 32 multiplies: what the sampler's time is) run while the
+    // coordinate loads are in flight; every wave has USED its (seed, offset) before it reaches the barrier ...
+    if (!noise) {
+#pragma unroll
+        for (int u = 0; u < K5_GPL; ++u) normal4(seed, off, g[u], eps[u]);
+        // whatever the scheduler does with the arithmetic: the two words are IN registers here, i.e. this wave's read of the
+        // offset has returned before it arrives at the barrier
+        asm volatile("" ::"s"((unsigned)off), "s"((unsigned)seed));
+    }
     __syncthreads();
-    if (live) {
+    // ... so the workgroup's ticket may be taken here, mid-kernel: the returning atomic (1-3 us with every CU issuing one)
+    // overlaps the wait for the coordinates and the stores instead of holding the finished workgroup on its CU
+    RngTicket ticket{0ull};
+    if (!noise) ticket = rng_take_ticket(rng_state);
+#pragma unroll
+    for (int u = 0; u < K5_GPL; ++u) {
+        if (!live[u]) continue;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float2 ka = beta_of(sp, beta, min(e0 + k, n_total - 1u), keep_add);
-            const float scaled = eps[k] * ka.y;      // noise = randn * beta.sqrt()
-            x[k] = ka.x * x[k] + scaled;             // (1 - beta).sqrt() * xyz + noise
+            const float2 ka = beta_of(sp, beta, min(e0[u] + k, n_total - 1u), keep_add);
+            const float scaled = eps[u][k] * ka.y;      // noise = randn * beta.sqrt()
+            x[u][k] = ka.x * x[u][k] + scaled;          // (1 - beta).sqrt() * xyz + noise
         }
-        if (full) {
-            *reinterpret_cast<float4*>(xyz + e0) = make_float4(x[0], x[1], x[2], x[3]);
+        if (full[u]) {
+            *reinterpret_cast<float4*>(xyz + e0[u]) = make_float4(x[u][0], x[u][1], x[u][2], x[u][3]);
         } else {
             for (int k = 0; k < 4; ++k)
-                if (e0 + k < n_total) xyz[e0 + k] = x[k];
+                if (e0[u] + k < n_total) xyz[e0[u] + k] = x[u][k];
         }
     }
-    if (!noise) rng_advance_by_last_block(rng_state, off);
+    if (!noise) rng_finish(rng_state, off + 1, ticket);
 }
 
 // K5+K4 fused diffusion step: a workgroup owns RB consecutive residues (RB*A*3 contiguous floats).
@@ -187,13 +266,16 @@ __global__ __launch_bounds__(256) void k54_diffuse_frames(float* __restrict__ xy
     const unsigned e_begin = r0 * rf, e_end = e_begin + nr * rf, n_total = n_res * rf;
     const unsigned g_begin = e_begin >> 2, g_end = (e_end + 3u) >> 2;  // float4 groups touching the block
     const unsigned nps = N * rf;                              // >= 9 >= 4 here (A >= 3)
-    uint64_t seed = 0, off = 0;
-    if (!noise) {
-        seed = rng_state[0];
-        off = rng_state[1];
-    }
+    __shared__ uint64_t rng_sh[2];
+    RngTicket ticket{0ull};
+    if (!noise) ticket = rng_read_and_take_ticket(rng_state, rng_sh);   // early ticket: see the helper
     const BetaSpan sp = beta_span_fill(beta, e_begin, e_end - e_begin, nps, n_res / N, keep_add);
     __syncthreads();
+    uint64_t seed = 0, off = 0;
+    if (!noise) {
+        seed = rng_sh[0];
+        off = rng_sh[1];
+    }
     for (unsigned g = g_begin + threadIdx.x; g < g_end; g += 256) {
         const unsigned e0 = g * 4u;
         const bool inner = e0 >= e_begin && e0 + 4u <= e_end;  // whole group owned by this block
@@ -251,7 +333,7 @@ __global__ __launch_bounds__(256) void k54_diffuse_frames(float* __restrict__ xy
             o[0] = t.x; o[1] = t.y; o[2] = t.z;
         }
     }
-    if (!noise) rng_advance_by_last_block(rng_state, off);
+    if (!noise) rng_finish(rng_state, off + 1, ticket);
 }
 
 // K55 -- the whole diffusion loop of BASELINE config 5 in ONE launch.  Kernel boundaries write back and
@@ -509,8 +591,8 @@ extern "C" int ps_diffuse_f32(float* xyz, const float* beta, int B, int n_per_st
     if (n_total == 0) return 0;
     if (n_total >= 0xFFFFFFF0ull) return (int)hipErrorInvalidValue;  // 32-bit index math (17 GB of coordinates)
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t groups = (n_total + 3) / 4;
-    return ps_launch(k5_diffuse, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, xyz, beta,
+    const size_t groups = (n_total + 3) / 4, per_wg = 256 * (size_t)K5_GPL;
+    return ps_launch(k5_diffuse, dim3((unsigned)((groups + per_wg - 1) / per_wg)), dim3(256), 0, s, xyz, beta,
                        (unsigned)n_total, (unsigned)n_per_struct, (unsigned)B, rng_state, noise);
 }
 

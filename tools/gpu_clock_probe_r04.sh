@@ -20,7 +20,7 @@ with open(o + "/clock_per_dispatch.csv", "w") as fh:
             continue
         ns = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
         cyc = float(r["Counter_Value"]) / 8
-        name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("void ", "").split("(")[0][:36].replace(",", ";")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:36].replace(",", ";")
         fh.write(f"{r['Dispatch_Id']},{name},{ns / 1e3:.1f},{cyc:.0f},{cyc / ns:.3f}\n")
 PY
 rm -rf $O/pmc

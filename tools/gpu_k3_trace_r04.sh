@@ -20,7 +20,7 @@ with open(o + "/k3_timeline.csv", "w") as fh:
     fh.write("kernel,start_us,duration_us,gap_us\n")
     for r in rows:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-        name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("void ", "").split("(")[0][:40].replace(",", ";")
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40].replace(",", ";")
         fh.write(f"{name},{(s - t0) / 1e3:.1f},{(e - s) / 1e3:.1f},{((s - prev_end) / 1e3 if prev_end else 0):.1f}\n")
         prev_end = e
 PY

@@ -15,7 +15,7 @@ for f in glob.glob(o + "/k5_trace/**/*kernel_trace.csv", recursive=True):
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 seq = {}
 for r in rows:
-    name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("void ", "").split("(")[0][:30]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:30]
     seq.setdefault(name, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for k, v in seq.items():
     if k[:1] == "k":
