@@ -197,6 +197,8 @@ int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_idx,
  *   1  the reference's order of operations (geometry.py:110-124, :64-66): three cross products, y / |b1| with a
  *      correctly rounded square root and an IEEE division, the device library's atan2f / acosf.  No entry more than
  *      1e-5 from the reference on well-conditioned inputs; about 2.5x the time.
+ *   2  [diagnostic] the arithmetic of 0 through the simple one-column kernel at every shape (what chains shorter than 100
+ *      residues take anyway): the cross-check kernel of the parity tests, like ps_k1_config.variant = 1.  Same bits as 0.
  */
 int ps_pairwise_angles_f32(const float* xyz, float* out,
                            int B, int N, int A,

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     const unsigned w = blockIdx.x;
     const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
     const int b = (int)(rest / (unsigned)n_chunks);
-    const int j = (int)tile * 256 + threadIdx.x;
+    const int j = (int)tile * (int)blockDim.x + threadIdx.x;   // a workgroup is 64, 128, 192 or 256 lanes wide (short chains)
     const int i0 = row_begin + (int)(rest % (unsigned)n_chunks) * IR;
     const int i1 = min(i0 + IR, row_end);
     const bool live = j < N;
@@ -150,7 +150,10 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
 //     end-of-kernel write-back, which is serial with everything (3-4 us of 57).
 //   * The arithmetic of the NC columns is evaluated step by step across the columns (dihedral4v_k3_n, angle3v_n).
 // Same operations per pair as the one-column kernel above: same bits.
-template <int NP, int SRC, int NC>
+// VEC = false (odd N, or an output that is not 4 * NC-byte aligned): the lane's NC columns are 64 apart instead of adjacent
+// (column = strip * 64 * NC + 64 * c + lane), so every store instruction writes 64 consecutive floats of one row -- no
+// alignment is needed at all -- at the price of NC dword stores per row instead of one vector store.
+template <int NP, int SRC, int NC, bool VEC>
 __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                  AtomSel sel, int row_begin, int row_end, int out_rows,
                                                  int out_row_origin, int CH, int n_strips, int n_chunks,
@@ -196,13 +199,14 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
             staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
         }
         if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
-        const int j0 = (strip * 64 + lane) * NC;
-        const bool live = j0 < N;                                 // N % NC == 0: a lane's columns are all in or all out
-        const int jc = live ? j0 : N - NC;
+        // VEC: NC adjacent columns (j0 .. j0 + NC - 1), N % NC == 0 so that they are all in or all out; otherwise NC columns 64 apart
+        const int j0 = VEC ? (strip * 64 + lane) * NC : strip * 64 * NC + lane;
+        constexpr int CSTEP = VEC ? 1 : 64;
+        const bool live = j0 < N;                                 // the lane's FIRST column (VEC: all of them)
         f3 pj[NC][NP];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float* sj = xb + (size_t)(jc + c) * (size_t)A * 3;
+            const float* sj = xb + (size_t)min(j0 + c * CSTEP, N - 1) * (size_t)A * 3;   // clamped: dead columns are never stored
 #pragma unroll
             for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
         }
@@ -245,7 +249,15 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
                 // from the scheduling barriers that interleave the columns' chains, and the chains serialise again
 #pragma unroll
                 for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
-                if (live) {
+                if constexpr (!VEC) {
+                    const int so = i * row_bytes;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc)
+                        if (j0 + 64 * cc < N) {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].x), rsrc, lane_off + 256 * cc, so, POL);
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].y), rsrc, lane_off + 256 * cc, so + row_bytes, POL);
+                        }
+                } else if (live) {
                     const int so = i * row_bytes;
                     if constexpr (NC == 4) {
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rsrc, lane_off, so, POL);
@@ -270,7 +282,12 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
                     else
                         v[cc] = angle3(p[0], p[1], p[2]);
                 }
-                if (live) {
+                if constexpr (!VEC) {
+                    const int so = i * row_bytes;
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc)
+                        if (j0 + 64 * cc < N) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc]), rsrc, lane_off + 256 * cc, so, POL);
+                } else if (live) {
                     const int so = i * row_bytes;
                     if constexpr (NC == 4)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0], v[1], v[2], v[3]}), rsrc, lane_off, so, POL);
@@ -297,7 +314,7 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     const unsigned w = blockIdx.x;   // 1-D grid as in k3_pairwise_angles
     const unsigned tile = w % (unsigned)n_tiles, rest = w / (unsigned)n_tiles;
     const int b = (int)(rest / (unsigned)n_chunks);
-    const int j = (int)tile * 256 + threadIdx.x;
+    const int j = (int)tile * (int)blockDim.x + threadIdx.x;   // a workgroup is 64, 128, 192 or 256 lanes wide (short chains)
     const int i0 = (int)(rest % (unsigned)n_chunks) * IR, i1 = min(i0 + IR, N);
     const bool live = j < N;
     const int jc = live ? j : N - 1;
@@ -578,7 +595,7 @@ inline int k3_rows_per_task(unsigned long long strips_x_structures, int rows, in
     return 2;
 }
 
-template <int NP, int SRC, int NC>
+template <int NP, int SRC, int NC, bool VEC>
 int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
                  int out_rows, int out_row_origin, hipStream_t s) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
@@ -594,54 +611,72 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     const size_t need = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8;   // one segment's rows, pair-interleaved
     const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
     static unsigned long long prepared[1] = {0};   // bit d: device d allows this kernel its dynamic LDS
-    if (const int e = k3_allow_big_lds(k3_sweep<NP, SRC, NC>, prepared)) return e;
-    return ps_launch(k3_sweep<NP, SRC, NC>, dim3(grid), dim3(1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
+    if (const int e = k3_allow_big_lds(k3_sweep<NP, SRC, NC, VEC>, prepared)) return e;
+    return ps_launch(k3_sweep<NP, SRC, NC, VEC>, dim3(grid), dim3(1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
                      out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
 }
 
+// One-column kernels: a workgroup as wide as the chain needs (whole waves, at most 256 lanes) -- with 256 lanes for a
+// 64-residue chain three of four waves computed pairs that do not exist.
+inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63) / 64); }
+
+// The per-CU sweep kernels pay two workgroup barriers and a staging pass per (structure, strip) segment and give a wave a
+// strip of 64 * NC columns: below ~100 residues a segment has fewer tasks than the workgroup has waves and most lanes of a
+// strip idle (N = 64: 143 us against 93 for the one-column kernel at 2^25 pairs; N = 16: 1427 against 282;
+// profiles/r04_k3_shapes.log) -- short chains stay with the one-column kernel.
+constexpr int K3_SWEEP_MIN_N = 100;
+
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
-           int out_rows, int out_row_origin, bool faithful, hipStream_t s) {
+           int out_rows, int out_row_origin, int mode, hipStream_t s) {   // mode = exact_angles of the C ABI
+    const bool faithful = mode == 1, simple = mode == 2;
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin;
+    const int thr1 = k3_one_column_threads(N);
     if (faithful) {
         const int IR = 16;
-        const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
+        const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (rows + IR - 1) / IR;
         const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel,
+        return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
                          row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
     }
     const uintptr_t al = reinterpret_cast<uintptr_t>(out);
     // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS
-    const bool fits = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX;
+    const bool fits = !simple && N >= K3_SWEEP_MIN_N && (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX;
     // four columns per lane only where the instantiation keeps its registers (three or two column-side points of a
     // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers)
     constexpr bool NC4 = NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 12 || SRC == 15;
     const bool ok4 = NC4 && fits && N % 4 == 0 && (al & 15u) == 0, ok2 = fits && N % 2 == 0 && (al & 7u) == 0;
+    // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
+    const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
     if (ok4 || ok2) {
-        // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
-        const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
         if constexpr (NC4) {
             if (ok4 && (!ok2 || w4 <= w2))
-                return launch_sweep<NP, SRC, 4>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+                return launch_sweep<NP, SRC, 4, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
         }
-        return launch_sweep<NP, SRC, 2>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+        return launch_sweep<NP, SRC, 2, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+    }
+    if (fits) {   // odd N or a misaligned output: the same sweep with the lane's columns 64 apart and dword stores
+        if constexpr (NC4) {
+            if (w4 <= w2) return launch_sweep<NP, SRC, 4, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+        }
+        return launch_sweep<NP, SRC, 2, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
     }
     const int IR = 16;
-    const int n_tiles = (N + 255) / 256, n_chunks = (rows + IR - 1) / IR;
+    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (rows + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    return ps_launch(k3_pairwise_angles<NP, SRC, false>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, N, A, sel,
+    return ps_launch(k3_pairwise_angles<NP, SRC, false>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
                      row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
 }
 
 template <int NP, int... SRCS>
 int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin,
-             int row_end, int out_rows, int out_row_origin, bool faithful, hipStream_t s) {
+             int row_end, int out_rows, int out_row_origin, int mode, hipStream_t s) {
     int rc = (int)hipErrorInvalidValue;
     (void)((srcmask == SRCS
-                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, faithful, s), true)
+                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, mode, s), true)
                 : false) ||
            ...);
     return rc;
@@ -653,7 +688,7 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
                                       const int* atom, int row_begin, int row_end, int out_rows, int out_row_origin,
                                       int exact_angles, void* stream) {
     if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
-    if (exact_angles != 0 && exact_angles != 1) return (int)hipErrorInvalidValue;
+    if (exact_angles < 0 || exact_angles > 2) return (int)hipErrorInvalidValue;
     if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
     if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
     if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
@@ -668,9 +703,9 @@ extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (n_points == 4)
         return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(
-            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, exact_angles != 0, s);
+            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, exact_angles, s);
     return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
-                                               out_row_origin, exact_angles != 0, s);
+                                               out_row_origin, exact_angles, s);
 }
 
 extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb,
@@ -679,10 +714,10 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                                              int exact_sqrt, int exact_angles, void* stream) {
     if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
         return (int)hipErrorInvalidValue;
-    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || (exact_angles != 0 && exact_angles != 1))
+    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || exact_angles < 0 || exact_angles > 2)
         return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    if (!exact_angles) {   // NC columns per lane where every store is aligned: N % NC == 0, 4 * NC-byte (masks: NC-byte) aligned planes
+    if (exact_angles == 0) {   // NC columns per lane where every store is aligned: N % NC == 0, 4 * NC-byte (masks: NC-byte) aligned planes
         uintptr_t alf = 0, alm = 0;
         for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
                               (const void*)theta, (const void*)phi})
@@ -690,7 +725,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
         for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
             alm |= reinterpret_cast<uintptr_t>(p);
         const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 16 + 3 * 256;   // one structure's rows: points + mask words; the strip's column mask bytes
-        const bool fits = need <= K3_LDS_MAX;
+        const bool fits = N >= K3_SWEEP_MIN_N && need <= K3_LDS_MAX;
         const bool ok4 = fits && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0;
         const bool ok2 = fits && N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0;
         if (ok4 || ok2) {
@@ -719,14 +754,14 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             return exact_sqrt ? go(k3_featurise<true, 2, false>, prep[2]) : go(k3_featurise<false, 2, false>, prep[3]);
         }
     }
-    const int IR = 16;
-    const int n_tiles = (N + 255) / 256, n_chunks = (N + IR - 1) / IR;
+    const int IR = 16, thr1 = k3_one_column_threads(N);
+    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (N + IR - 1) / IR;
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     auto go = [&](auto kernel) {
-        return ps_launch(kernel, dim3((unsigned)n_wg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
+        return ps_launch(kernel, dim3((unsigned)n_wg), dim3(thr1), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
                          d_ca, d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
     };
-    if (exact_angles) return exact_sqrt ? go(k3_inter_residue_geometry<true, true>) : go(k3_inter_residue_geometry<false, true>);
+    if (exact_angles == 1) return exact_sqrt ? go(k3_inter_residue_geometry<true, true>) : go(k3_inter_residue_geometry<false, true>);
     return exact_sqrt ? go(k3_inter_residue_geometry<true, false>) : go(k3_inter_residue_geometry<false, false>);
 }

@@ -400,11 +400,12 @@ def backbone_dihedrals(xyz: torch.Tensor, chain_idx: torch.Tensor, residue_mask:
 
 def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence[int], n_points: int, *,
                     row_begin: int = 0, row_end: Optional[int] = None, compact: bool = False,
-                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                    out: Optional[torch.Tensor] = None, _one_column: bool = False) -> torch.Tensor:
     """K3.  n_points = 4: dihedral, 3: planar angle, over points (slots_i of residue i ++ slots_j of residue j).
     Only residue rows [row_begin, row_end) are computed, with K1's row addressing: into rows [row_begin, row_end) of
     a full-size (B, N, N) buffer (``out`` may supply it, e.g. the destination of an all-gather) or, with ``compact``,
-    into a (B, row_end - row_begin, N) buffer."""
+    into a (B, row_end - row_begin, N) buffer.  ``_one_column`` (tests): the fast arithmetic through the simple one-column
+    kernel at any shape (``exact_angles = 2`` of the C ABI, diagnostic)."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     slots = [int(s) for s in slots_i] + [int(s) for s in slots_j]
@@ -426,7 +427,7 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
         if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
             rc = _lib.load().ps_pairwise_angles_f32(
                 _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
-                _lib.get_exact_angles(xyz.device), _stream(xyz))
+                2 if _one_column else _lib.get_exact_angles(xyz.device), _stream(xyz))
     _lib.check(rc, "ps_pairwise_angles_f32")
     return out
 

@@ -1176,11 +1176,13 @@ def test_k3_row_ranges_compact_and_in_place(SB, N):
         ops.pairwise_angles(xg, [1, 4], [1, 4], 4, out=torch.empty(3, N, N + 1, device="cuda"))
 
 
-@pytest.mark.parametrize("N", [6, 64, 130, 256, 384, 512, 516])
+@pytest.mark.parametrize("N", [6, 64, 101, 130, 255, 256, 384, 511, 512, 516])
 def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
     """The per-CU sweep kernels (two / four column residues per lane, LDS-staged rows, pulled tasks, arithmetic
     interleaved across the columns) evaluate the same operations per pair as the one-column kernel: same bits.  The
-    one-column kernel is reached through a 4-byte-misaligned output; full launches and an odd row range."""
+    one-column kernel is asked for explicitly (`exact_angles = 2`, diagnostic); the dispatcher's pick for an aligned output
+    (vector stores for even N, the 64-apart column layout with dword stores for odd N) and for a 4-byte-misaligned output
+    (always the dword layout; short chains: the one-column kernel) are both held to it; full launches and an odd row range."""
     from protstruc_amd import ops
     B = 3
     xyz, _ = synth(900 + N, B, N)
@@ -1191,10 +1193,11 @@ def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
     splits = [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (4, [2], [0, 1, 2]), (4, [1], [4, 1, 0]), (4, [0, 1], [2, 3]),
               (4, [0, 1, 2, 3], []), (4, [], [0, 1, 2, 3]), (3, [1, 4], [4]), (3, [1], [1, 4]), (3, [], [0, 1, 2]), (3, [4, 1, 0], [])]
     for npts, si, sj in splits:
+        one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
         big = torch.full((B * N * N + 1,), 7.0, device="cuda")
-        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned -> one column per lane
+        mis = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned: columns 64 apart, dword stores
         fast = ops.pairwise_angles(xg, si, sj, npts)
-        assert same(fast, one), (npts, si, sj)
+        assert same(fast, one) and same(mis, one), (npts, si, sj)
         assert big[0] == 7.0
         if N > 8:
             r0, r1 = 3, N - 2                                                      # odd number of rows, odd first row
@@ -1260,8 +1263,8 @@ def test_k3_exact_angles_mode(SB):
     import ctypes
     arr = (ctypes.c_int * 4)
     xg = xyz[:1].contiguous().cuda(); out = torch.empty(1, N, N, device="cuda")
-    rc = lib.ps_pairwise_angles_f32(xg.data_ptr(), out.data_ptr(), 1, N, 15, 4, arr(0, 0, 1, 1), arr(1, 4, 1, 4), 0, N, N, 0, 2, None)
-    assert rc == 1                                                        # exact_angles outside {0, 1}: refused before any launch
+    rc = lib.ps_pairwise_angles_f32(xg.data_ptr(), out.data_ptr(), 1, N, 15, 4, arr(0, 0, 1, 1), arr(1, 4, 1, 4), 0, N, N, 0, 3, None)
+    assert rc == 1                                                        # exact_angles outside {0, 1, 2}: refused before any launch
 
 
 def test_k3_planar_angle_collinear_and_extreme_arms(SB):
@@ -1313,10 +1316,11 @@ def test_k3_sweep_kernels_long_chains(SB, N):
     xg = xyz.cuda()
     same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
     for npts, si, sj in [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (3, [1, 4], [4])]:
+        one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
         big = torch.full((B * N * N + 1,), 7.0, device="cuda")
-        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned -> one column per lane
+        mis = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned: dword-store layout
         fast = ops.pairwise_angles(xg, si, sj, npts)
-        assert same(fast, one), (npts, si, sj)
+        assert same(fast, one) and same(mis, one), (npts, si, sj)
         part = ops.pairwise_angles(xg, si, sj, npts, row_begin=N // 3, row_end=N // 3 + 777, compact=True)   # a shard
         assert same(part, one[:, N // 3:N // 3 + 777])
     geo = SB.from_xyz(xyz).inter_residue_geometry()
@@ -1325,8 +1329,9 @@ def test_k3_sweep_kernels_long_chains(SB, N):
 
 def test_k3_differential_fuzz(SB):
     """Random shapes, point splits, row ranges and output forms: the sweep kernels (and whatever the dispatcher picks for
-    the shape -- four or two columns per lane, the one-column kernel for odd N) against the one-column kernel reached
-    through a misaligned buffer, bit for bit; nothing outside the requested rows is written."""
+    the shape -- four or two columns per lane with vector stores, the 64-apart layout with dword stores for odd N, the
+    one-column kernel for short chains) against the one-column kernel asked for explicitly, bit for bit; nothing outside
+    the requested rows is written."""
     from protstruc_amd import ops
     rng = np.random.default_rng(20260404)
     same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
@@ -1345,8 +1350,10 @@ def test_k3_differential_fuzz(SB):
         if trial % 7 == 0 and N > 2:
             xyz[-1, 1] = xyz[-1, 0]
         xg = xyz.cuda()
-        big = torch.full((B * N * N + 1,), 7.0, device="cuda")
-        one = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))
+        one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
+        if trial % 4 == 1:          # the misaligned-output path as well
+            big = torch.full((B * N * N + 1,), 7.0, device="cuda")
+            assert same(ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N)), one) and big[0] == 7.0
         r0 = int(rng.integers(0, N)); r1 = int(rng.integers(r0, N + 1))
         if trial % 3 == 0:
             r0, r1 = 0, N
