@@ -36,51 +36,7 @@ __global__ __launch_bounds__(1024) void k(float* out, int trips, float seed) {
     if (acc.x + acc.y == 12345.678f) out[threadIdx.x] = acc.x;
 }
 
-// atan2_k3 on NC column pairs at once, step by step across the columns (NC independent chains in program order)
-template <int NC>
-__device__ __forceinline__ void atan2_k3_vn(const f32x2 (&y)[NC], const f32x2 (&x)[NC], f32x2 (&r)[NC]) {
-    auto k2 = [](float c) { return f32x2{c, c}; };
-    f32x2 ax[NC], ay[NC], a[NC], s[NC], p[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        ax[c] = f32x2{fabsf(x[c].x), fabsf(x[c].y)}; ay[c] = f32x2{fabsf(y[c].x), fabsf(y[c].y)};
-        const f32x2 mx = {fmaxf(fmaxf(ax[c].x, ay[c].x), 1.17549435e-38f), fmaxf(fmaxf(ax[c].y, ay[c].y), 1.17549435e-38f)};
-        const f32x2 mn = {fminf(ax[c].x, ay[c].x), fminf(ax[c].y, ay[c].y)};
-        a[c] = mn * f32x2{__builtin_amdgcn_rcpf(mx.x), __builtin_amdgcn_rcpf(mx.y)};
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) s[c] = a[c] * a[c];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(k2(0.0028340641874819994f), s[c], k2(-0.016005029901862144f));
-    const float co[7] = {0.042587608098983765f, -0.07495445758104324f, 0.10636754333972931f, -0.14202570915222168f,
-                         0.19992484152317047f, -0.3333306610584259f, 1.0f};
-#pragma unroll
-    for (int t = 0; t < 7; ++t) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(p[c], s[c], k2(co[t]));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) r[c] = a[c] * p[c];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const f32x2 rq = k2(1.5707963267948966f) - r[c];
-        r[c].x = (ay[c].x > ax[c].x) ? rq.x : r[c].x;
-        r[c].y = (ay[c].y > ax[c].y) ? rq.y : r[c].y;
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        const f32x2 rh = k2(3.141592653589793f) - r[c];
-        r[c].x = (__float_as_uint(x[c].x) >> 31) ? rh.x : r[c].x;
-        r[c].y = (__float_as_uint(x[c].y) >> 31) ? rh.y : r[c].y;
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        r[c] = __builtin_elementwise_fma(x[c], k2(0.0f), r[c]);
-        r[c] = f32x2{copysignf(r[c].x, y[c].x), copysignf(r[c].y, y[c].y)};
-    }
-}
+// the column-interleaved atan2 (atan2_k3_vn) is the product's, ps_common.hpp
 __global__ __launch_bounds__(1024) void k_il(float* out, int trips, float seed) {
     f3 cj[4], dj[4];
     for (int c = 0; c < 4; ++c) {
