@@ -186,6 +186,19 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
         const int r_lo = row_begin + c_lo * CH, r_hi = min(row_begin + c_hi * CH, row_end);
         const float* xb = xyz + (size_t)b * N * (size_t)A * 3;   // uniform
         __syncthreads();                                          // the previous segment's readers are done
+        // the column-side points are requested BEFORE the rows are staged: the two global-memory latencies of a segment's
+        // set-up overlap instead of following each other (a 128-residue segment computes for ~6 us; its set-up was ~2)
+        // VEC: NC adjacent columns (j0 .. j0 + NC - 1), N % NC == 0 so that they are all in or all out; otherwise NC columns 64 apart
+        const int j0 = VEC ? (strip * 64 + lane) * NC : strip * 64 * NC + lane;
+        constexpr int CSTEP = VEC ? 1 : 64;
+        const bool live = j0 < N;                                 // the lane's FIRST column (VEC: all of them)
+        f3 pj[NC][NP];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float* sj = xb + (size_t)min(j0 + c * CSTEP, N - 1) * (size_t)A * 3;   // clamped: dead columns are never stored
+#pragma unroll
+            for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
+        }
         if (NPI > 0 && (b != staged_b || r_lo != staged_lo || r_hi != staged_hi)) {
             float* rb = reinterpret_cast<float*>(k3_rowbuf);
             const int n_el = (r_hi - r_lo) * NPI * 3;
@@ -199,17 +212,6 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
             staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
         }
         if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
-        // VEC: NC adjacent columns (j0 .. j0 + NC - 1), N % NC == 0 so that they are all in or all out; otherwise NC columns 64 apart
-        const int j0 = VEC ? (strip * 64 + lane) * NC : strip * 64 * NC + lane;
-        constexpr int CSTEP = VEC ? 1 : 64;
-        const bool live = j0 < N;                                 // the lane's FIRST column (VEC: all of them)
-        f3 pj[NC][NP];
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float* sj = xb + (size_t)min(j0 + c * CSTEP, N - 1) * (size_t)A * 3;   // clamped: dead columns are never stored
-#pragma unroll
-            for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
-        }
         __syncthreads();
         // the segment's rows as one buffer: uniform base, the lane's constant byte offset, the row's byte offset as a scalar
         float* obase = out + ((size_t)b * out_rows + (size_t)(r_lo - out_row_origin)) * N;
@@ -586,13 +588,13 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     }
 }
 
-// rows per task (even).  8 by default; fewer when the list would not give every CU's 16 waves a few tasks each
-inline int k3_rows_per_task(unsigned long long strips_x_structures, int rows, int cus) {
-    for (int ch : {8, 4}) {
-        const unsigned long long tasks = strips_x_structures * (unsigned long long)((rows + ch - 1) / ch);
-        if (tasks >= (unsigned long long)cus * 16 * 4) return ch;
-    }
-    return 2;
+// Rows per task (even, 2..8).  The 16 waves of a workgroup pull the tasks of one (structure, strip) segment at a time, and
+// the pulling only evens out the SIMD arbiter's oldest-first order if a segment has several tasks per wave: a segment of
+// `rows` rows gets about 64 tasks (N = 512: 8 rows per task, 256: 4, 128: 2; with one task per wave a 128-residue segment
+// ended when its slowest wave did: 61 -> 5x us at 2^25 pairs, profiles/r04_k3_shapes.log).  A task costs one LDS atomic.
+inline int k3_rows_per_task(int rows, int min_rows) {
+    const int ch = (rows / 64) & ~1;
+    return std::min(8, std::max(min_rows, ch));
 }
 
 template <int NP, int SRC, int NC, bool VEC>
@@ -601,7 +603,7 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin, cus = k3_cu_count();
     const int n_strips = (N + 64 * NC - 1) / (64 * NC);
-    const int CH = k3_rows_per_task((unsigned long long)n_strips * B, rows, cus);
+    const int CH = k3_rows_per_task(rows, 2);
     const int n_chunks = (rows + CH - 1) / CH;
     const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
@@ -733,7 +735,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             const int NC = (K3_FEATURISE_NC4 && ok4 && (!ok2 || w4 <= w2)) ? 4 : 2;
             const int cus = k3_cu_count();
             const int n_strips = (N + 64 * NC - 1) / (64 * NC);
-            const int CH = k3_rows_per_task((unsigned long long)n_strips * B, N, cus);
+            const int CH = k3_rows_per_task(N, 4);   // its 16-byte mask stores carry four rows per instruction
             const int n_chunks = (N + CH - 1) / CH;
             const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
             if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
