@@ -64,6 +64,7 @@ inline int k3_allow_big_lds(K kernel, unsigned long long (&done)[1]) {
 constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-thread workgroups (two waves per SIMD, 256 VGPRs each)
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
+constexpr size_t K3_LDS_TWO_PER_CU = 80 * 1024 - 256;   // exactly two such workgroups fit a CU (three would need 240 KB)
 
 template <int NP, int SRC, bool FAITHFUL>
 __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restrict__ xyz, float* __restrict__ out,
@@ -607,14 +608,20 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     const int n_chunks = (rows + CH - 1) / CH;
     const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    // every CU one workgroup; short lists: at least 4 tasks per workgroup (its 16 waves pull them)
-    const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + cus - 1) / cus, 4ull);
-    const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
     const size_t need = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8;   // one segment's rows, pair-interleaved
-    const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
+    // Every CU one 1024-thread workgroup -- or, when a workgroup would walk four or more (structure, strip) segments (chains
+    // of ~128 residues in large batches), TWO 512-thread workgroups: a segment's set-up (two barriers, the global-load latency
+    // of its rows and column points) idles all of a workgroup's waves for ~1.8 us, and a second workgroup on the CU computes
+    // meanwhile.  Their LDS requests admit exactly two per CU.  Short lists: at least 4 tasks per workgroup.
+    const unsigned long long segs = (unsigned long long)n_strips * B;
+    const bool two = segs >= 4ull * cus * 2 && need <= K3_LDS_TWO_PER_CU;
+    const unsigned slots = (unsigned)cus * (two ? 2u : 1u);
+    const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + slots - 1) / slots, 4ull);
+    const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+    const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
     static unsigned long long prepared[1] = {0};   // bit d: device d allows this kernel its dynamic LDS
     if (const int e = k3_allow_big_lds(k3_sweep<NP, SRC, NC, VEC>, prepared)) return e;
-    return ps_launch(k3_sweep<NP, SRC, NC, VEC>, dim3(grid), dim3(1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
+    return ps_launch(k3_sweep<NP, SRC, NC, VEC>, dim3(grid), dim3(two ? 512 : 1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
                      out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
 }
 
