@@ -136,6 +136,51 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     }
 }
 
+// Short chains (N <= 32: peptide batches).  A 64-lane wave of the one-column kernel covers 64 column residues, so a
+// 16-residue chain uses a quarter of it.  Here a wave owns one structure and its lanes are (row group, column): Npad = 16 or
+// 32 columns x G = 64 / Npad rows at a time; the row-side points are per-lane vector loads (the Npad lanes of a row group
+// share an address), four rows per trip (two packed pairs, their chains interleaved), and a store instruction writes G
+// consecutive rows of the structure.  Same arithmetic per pair as the one-column kernel: same bits.
+template <int NP, int SRC>
+__global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, float* __restrict__ out, int B, int N, int A,
+                                                AtomSel sel, int row_begin, int row_end, int out_rows, int out_row_origin,
+                                                int lg_npad) {
+    const int lane = threadIdx.x & 63;
+    const int b = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);   // one wave per structure
+    if (b >= B) return;
+    const int npad = 1 << lg_npad, G = 64 >> lg_npad;
+    const int j = lane & (npad - 1), ri = lane >> lg_npad;
+    const bool live_j = j < N;
+    const float* xb = xyz + (size_t)b * N * (size_t)A * 3;
+    const float* sj = xb + (size_t)min(j, N - 1) * (size_t)A * 3;
+    f3 pj[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) pj[k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
+    float* ob = out + (size_t)b * out_rows * N;
+    for (int i0 = row_begin + ri; i0 < row_end; i0 += 4 * G) {     // rows i0, i0 + G, i0 + 2G, i0 + 3G of this lane
+        f3v P[NP][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float* sa = xb + (size_t)min(i0 + 2 * h * G, N - 1) * (size_t)A * 3;
+            const float* sb2 = xb + (size_t)min(i0 + (2 * h + 1) * G, N - 1) * (size_t)A * 3;
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                P[k][h] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(sa + sel.atom[k] * 3), load3(sb2 + sel.atom[k] * 3));
+        }
+        f32x2 v[2];
+        if constexpr (NP == 4)
+            dihedral4v_k3_n<2>(P[0], P[1], P[2], P[3], v);
+        else
+            angle3v_n<2>(P[0], P[1], P[2], v);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ia = i0 + 2 * h * G, ib = ia + G;
+            if (live_j && ia < row_end) ob[(size_t)(ia - out_row_origin) * N + j] = v[h].x;
+            if (live_j && ib < row_end) ob[(size_t)(ib - out_row_origin) * N + j] = v[h].y;
+        }
+    }
+}
+
 // The sweep for even N (round 4): ONE 1024-thread workgroup per CU, NC = 2 or 4 consecutive column residues per lane
 // (8- or 16-byte stores), two rows per trip in the halves of float2 registers.
 //   * Work list: task t = (b * n_strips + strip) * n_chunks + chunk = CH rows x one strip of 64 * NC columns of one
@@ -649,6 +694,12 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
         return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
                          row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+    }
+    if (!simple && N <= 32) {   // peptide batches: lanes = (row group, column), one wave per structure
+        const unsigned long long n_wg = ((unsigned long long)B + 3) / 4;
+        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        return ps_launch(k3_small<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, B, N, A, sel, row_begin, row_end,
+                         out_rows, out_row_origin, N <= 16 ? 4 : 5);
     }
     const uintptr_t al = reinterpret_cast<uintptr_t>(out);
     // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS

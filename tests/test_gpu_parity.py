@@ -1367,6 +1367,31 @@ def test_k3_differential_fuzz(SB):
             assert (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
 
 
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 8, 15, 16, 17, 31, 32])
+def test_k3_short_chain_kernel_bit_identical_to_the_one_column_kernel(SB, N):
+    """Peptide batches (N <= 32) take a kernel of their own -- one wave per structure, lanes = (row group, column), four rows
+    per trip -- with the one-column kernel's arithmetic: same bits, for every point split, batch sizes that fill a
+    workgroup's four waves partly, row ranges, compact and in-place outputs."""
+    from protstruc_amd import ops
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    splits = [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (4, [2], [0, 1, 2]), (4, [0, 1, 2, 3], []), (4, [], [0, 1, 2, 3]),
+              (3, [1, 4], [4]), (3, [1], [1, 4]), (3, [], [0, 1, 2]), (3, [4, 1, 0], [])]
+    for B in (1, 5, 9):
+        xyz, _ = synth(1300 + N + B, B, N)
+        if N > 1:
+            xyz[0, N // 2] = float("nan")
+            xyz[B - 1, 1] = xyz[B - 1, 0]
+        xg = xyz.cuda()
+        for npts, si, sj in splits:
+            one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
+            assert same(ops.pairwise_angles(xg, si, sj, npts), one), (N, B, npts, si, sj)
+            r0, r1 = N // 3, N - N // 4
+            assert same(ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True), one[:, r0:r1])
+            buf = torch.full((B, N, N), 321.0, device="cuda")
+            ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
+            assert same(buf[:, r0:r1], one[:, r0:r1]) and (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+
+
 def test_k3_inside_a_captured_graph(SB):
     """The sweep kernels ask for more than 64 KB of dynamic LDS, which has to be allowed once per kernel
     (hipFuncSetAttribute at an instantiation's first launch, possibly a captured one: legal during capture --
