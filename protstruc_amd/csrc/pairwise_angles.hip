@@ -136,9 +136,9 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
     }
 }
 
-// Short chains (N <= 32: peptide batches).  A 64-lane wave of the one-column kernel covers 64 column residues, so a
-// 16-residue chain uses a quarter of it.  Here a wave owns one structure and its lanes are (row group, column): Npad = 16 or
-// 32 columns x G = 64 / Npad rows at a time; the row-side points are per-lane vector loads (the Npad lanes of a row group
+// Short chains (N <= 64; peptide batches).  A 64-lane wave of the one-column kernel covers 64 column residues, so a
+// 16-residue chain uses a quarter of it.  Here a wave owns one structure and its lanes are (row group, column): Npad = 16, 32
+// or 64 columns x G = 64 / Npad rows at a time; the row-side points are per-lane vector loads (the Npad lanes of a row group
 // share an address), four rows per trip (two packed pairs, their chains interleaved), and a store instruction writes G
 // consecutive rows of the structure.  Same arithmetic per pair as the one-column kernel: same bits.
 template <int NP, int SRC>
@@ -679,6 +679,7 @@ inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63)
 // strip idle (N = 64: 143 us against 93 for the one-column kernel at 2^25 pairs; N = 16: 1427 against 282;
 // profiles/r04_k3_shapes.log) -- short chains stay with the one-column kernel.
 constexpr int K3_SWEEP_MIN_N = 100;
+constexpr int K3_SMALL_MAX_N = 32;    // k3_small: one wave per structure (33..64 measured: no better than the one-column kernel)
 
 template <int NP, int SRC>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
@@ -695,11 +696,11 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
         return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
                          row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
     }
-    if (!simple && N <= 32) {   // peptide batches: lanes = (row group, column), one wave per structure
+    if (!simple && N <= K3_SMALL_MAX_N) {   // short chains: lanes = (row group, column), one wave per structure
         const unsigned long long n_wg = ((unsigned long long)B + 3) / 4;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
         return ps_launch(k3_small<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, B, N, A, sel, row_begin, row_end,
-                         out_rows, out_row_origin, N <= 16 ? 4 : 5);
+                         out_rows, out_row_origin, N <= 16 ? 4 : N <= 32 ? 5 : 6);
     }
     const uintptr_t al = reinterpret_cast<uintptr_t>(out);
     // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS

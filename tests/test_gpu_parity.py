@@ -1367,9 +1367,9 @@ def test_k3_differential_fuzz(SB):
             assert (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
 
 
-@pytest.mark.parametrize("N", [1, 2, 3, 5, 8, 15, 16, 17, 31, 32])
+@pytest.mark.parametrize("N", [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64])
 def test_k3_short_chain_kernel_bit_identical_to_the_one_column_kernel(SB, N):
-    """Peptide batches (N <= 32) take a kernel of their own -- one wave per structure, lanes = (row group, column), four rows
+    """Short chains (N <= 64) take a kernel of their own -- one wave per structure, lanes = (row group, column), four rows
     per trip -- with the one-column kernel's arithmetic: same bits, for every point split, batch sizes that fill a
     workgroup's four waves partly, row ranges, compact and in-place outputs."""
     from protstruc_amd import ops
