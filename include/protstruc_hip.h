@@ -62,7 +62,7 @@ const char* ps_error_string(int code);
  *   DIAGNOSTIC -- kept only so that closed A/B comparisons and the cross-check tests stay reproducible; no caller needs
  *   them and the defaults (0) are the product:
  *       variant = 1 (the simple kernels everywhere: the cross-check of the parity tests), flat = 0 / 2 / 4 and
- *       rowphase = 1 / 2 (force or forbid a kernel family), store_nt = 1 (non-temporal stores: slower),
+ *       rowphase = 1 / 2 (force or forbid a kernel family; + 16: an A/B switch of the row-phase kernel), store_nt = 1 (non-temporal stores: slower),
  *       flat_fl_log2 = 4 / 5 (the small granules of round 3's bounded A/B), experiment (must be 0: refused by the
  *       product library).
  */
@@ -88,7 +88,8 @@ typedef struct ps_k1_config {
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
     int rowphase;         /* [diagnostic] row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
                              dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel; 1 also for A = 14, 15, 16,
-                             24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead) */
+                             24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead).  Bits 4..7 (value / 16) are A/B
+                             switches of that kernel: 16 = the A = 1 seam slots written element-wise from both rows (round 3) */
     int experiment;       /* [diagnostic] must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
                              run that writes WRONG values, +16 = fully unrolled group loop */

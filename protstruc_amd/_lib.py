@@ -140,7 +140,7 @@ _K1_KEYS = {   # tuning key -> (struct field, lowest, highest)
     "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", 0, 120),
     "k1_flat_cpw": ("flat_cpw", 1, 64), "k1_flat_lds_pad_kb": ("flat_lds_pad_kb", 0, 100),
     "k1_jt": ("jt", 0, 128), "k1_xcd_remap": ("xcd_remap", 0, 1), "k1_store_nt": ("store_nt", 0, 1),
-    "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 2), "k1_experiment": ("experiment", 0, 31),
+    "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 255), "k1_experiment": ("experiment", 0, 31),
 }
 _k1_lock = threading.RLock()
 _k1_table = {}   # device index -> {field: value}

@@ -1221,11 +1221,15 @@ __host__ __device__ inline int rowphase_maxres(int A) { return (4 * 512 + 2) / (
 // in a descriptor + this lane's constant element offset: full slots spend no vector work on addresses); PH = the row's
 // phase.  The row atom of every element arrives as one
 // ds_read_b128 whose fourth component is that atom's mask bit (0 / 1 as an integer), so the mask costs no second lookup.
-template <int ACT, bool EXACT, int PH>
+// HEAD (A = 1 only, the slots of u = 0): the window elements in front of the row's first element stand for the previous
+// row's last elements (see the kernel), whose row atom is the previous row's: `xim_off` = -16 in the lane that owns slot 0
+// (the previous row's atom sits right in front of this row's in LDS), 0 in every other lane.
+template <int ACT, bool EXACT, int PH, bool HEAD>
 __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, const float (&col)[7][3],
                                               const uint32_t (&aoff)[7], uint32_t cm, uint32_t valid,
                                               float* __restrict__ od_, uint8_t* __restrict__ om_, bool wd, bool wm,
-                                              const run16& rund, const run16& runm, unsigned so) {
+                                              const run16& rund, const run16& runm, unsigned so, int xim_off,
+                                              bool skip_tail) {
     // wd / wm: whether the distance / mask plane is produced (uniform); the pointers are only meaningful when set
     float* od = wd ? od_ : nullptr;
     uint8_t* om = wm ? om_ : nullptr;
@@ -1235,11 +1239,14 @@ __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, c
     if (vm == 0u) return;
     float v[4];
     uint32_t rowbytes = 0;                             // byte k = mask bit of element k's row atom
-    float4 xi0;
-    if (ACT == 1) xi0 = *reinterpret_cast<const float4*>(xi_row);
+    float4 xi0, xim;
+    if (ACT == 1) {
+        xi0 = *reinterpret_cast<const float4*>(xi_row);
+        if (HEAD && PH > 0) xim = *reinterpret_cast<const float4*>(xi_row + xim_off);
+    }
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float4 xi = (ACT == 1) ? xi0 : *reinterpret_cast<const float4*>(xi_row + aoff[WO + k]);
+        const float4 xi = (ACT == 1) ? ((HEAD && k < PH) ? xim : xi0) : *reinterpret_cast<const float4*>(xi_row + aoff[WO + k]);
         v[k] = dist_pp<EXACT>(xi, make_float4(col[WO + k][0], col[WO + k][1], col[WO + k][2], 0.f));
         rowbytes |= __float_as_uint(xi.w) << (8 * k);
     }
@@ -1248,7 +1255,9 @@ __device__ __forceinline__ void rowphase_slot(const char* __restrict__ xi_row, c
         if (wd) rund.store(4u * so, 0u, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                                    __float_as_uint(v[3])));
         if (wm) runm.store4(so, 0u, mw);
-    } else {   // the slot that holds a row's start or end: this row's elements only
+    } else {   // the slot that holds a row's start or end: this row's elements only.  skip_tail (uniform, A = 1): the next
+               // row of this row chunk writes the slot whole (its head slot carries this row's last elements)
+        if (ACT == 1 && skip_tail && !(vm & 8u)) return;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if ((vm >> k) & 1u) {
@@ -1264,7 +1273,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                             int N, int A_rt, int row_begin, int row_end, int out_rows,
                                                             int out_row_origin, int IR, int n_tiles, int spt,
-                                                            int n_ichunks, int lpg_log2, int xcd_remap) {
+                                                            int n_ichunks, int lpg_log2, int xcd_remap, int flags) {
     using T = RowPhase<ACT>;
     typedef typename T::bits_t bits_t;
     constexpr int W = T::W;
@@ -1272,7 +1281,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     const int AA = A * A;
     const int maxres = rowphase_maxres(A);
     extern __shared__ __attribute__((aligned(16))) char smem_rp[];
-    float4* sxi = reinterpret_cast<float4*>(smem_rp);                   // [IR * A] row atoms: x, y, z, mask bit
+    float4* sxi = reinterpret_cast<float4*>(smem_rp) + (ACT == 1 ? 1 : 0);   // [IR * A] row atoms: x, y, z, mask bit (A = 1: one
+                                                                        // atom of padding in front, "row -1" of the seam logic)
     bits_t* smj = reinterpret_cast<bits_t*>(sxi + IR * A);              // [maxres] column mask bits
     float* sxj = reinterpret_cast<float*>(smj + maxres);                // [maxres * A * 3] column coordinates, as in HBM
 
@@ -1287,6 +1297,16 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     const int i0 = row_begin + (int)(rest % (unsigned)n_ichunks) * IR;
     const int in = min(IR, row_end - i0);
     const int nel = N * AA;                                             // elements of one row run
+    // Seams (A = 1).  Where a row run does not end on the 16-byte grid, one slot holds the end of row R and the start of
+    // row R + 1.  Written from both sides it costs two visits of element-wise stores (up to 3 dword + 3 byte store
+    // instructions each, one lane active): with the 2 KB rows of a CA trace that was 6 of the 10 store instructions of a row
+    // (N = 501).  So the window elements in FRONT of a row's first element (t < 0: only the lane that owns slot 0 has them)
+    // stand for the previous row's last elements -- column atoms of residues N + t, row atom = the previous row's, valid for
+    // every row but the first of the chunk (`validp`) -- which makes the head slot a full slot like any other, and the
+    // previous row skips its partial tail slot (skip_tail); only the chunk's first head and last tail are still written
+    // element-wise.  (For the longer rows of A >= 3 the seams are 6 % of the store instructions and the same change
+    // measured +-1 %, for 44 more registers: not taken.)  flags bit 0 [diagnostic]: off, as in round 3.
+    const bool merge = ACT == 1 && (nel & 3) != 0 && nel >= 8 && !(flags & 1);
     const int nslots = (nel + 3 + ((nel & 3) == 0 ? 0 : (nel & 3) == 2 ? 2 : 3)) / 4;   // slots a row can touch, over the phases that occur
     const int s0 = (int)tile * spt, s1 = min(s0 + spt, nslots);
     // Short rows (a CA trace of 512 residues is 128 slots): the 256 lanes split into 256 >> lpg_log2 row groups of
@@ -1307,6 +1327,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
             const int atom = f / 3, comp = f - atom * 3;
             li[atom * 4 + comp] = gi[f];
         }
+        if (ACT == 1 && tid == 0) sxi[-1] = make_float4(0.f, 0.f, 0.f, 0.f);   // "row -1": read by the first row's head slot,
+                                                     // its mask word is OR-ed in before the valid bytes are picked
         for (int f = tid; f < in * A; f += 256)      // fourth component: the row atom's mask bit
             reinterpret_cast<uint32_t*>(sxi)[f * 4 + 3] = amask ? (amask[((size_t)b * N + i0) * A + f] != 0 ? 1u : 0u) : 1u;
         for (int r = tid; r < nres; r += 256) {
@@ -1329,6 +1351,8 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     // per-lane pattern: column atom, row-atom offset, column mask bit and validity of every window element
     float col[T::SPL][7][3];
     uint32_t aoff[T::SPL][7], cm[T::SPL], valid[T::SPL], so[T::SPL];
+    uint32_t validp = 0;                               // A = 1: valid[0] with the previous row's last elements switched on
+    const int xim_off = (ACT == 1 && merge && s0 + sl == 0) ? -(int)sizeof(float4) : 0;
 #pragma unroll
     for (int u = 0; u < T::SPL; ++u) {
         const int s = s0 + LPG * u + sl;
@@ -1351,9 +1375,18 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                 aoff[u][wi] = a * (unsigned)sizeof(float4);
                 cm[u] |= (ok ? (uint32_t)((smj[j - (unsigned)j_lo] >> c) & 1u) : 0u) << wi;
                 valid[u] |= (ok ? 1u : 0u) << wi;
+                if (ACT == 1 && u == 0 && wi < T::W0 && merge && s == 0) {   // t = wi - 3 < 0: residue N + t of the previous row
+                    const size_t ja = (size_t)b * N + (size_t)(N + t);      // (A = 1: element = residue; from L2: the last
+                    col[u][wi][0] = xyz[ja * 3];                            //  residues are not among tile 0's staged ones
+                    col[u][wi][1] = xyz[ja * 3 + 1];                        //  when a row has several tiles)
+                    col[u][wi][2] = xyz[ja * 3 + 2];
+                    cm[u] |= (amask ? (amask[ja] != 0 ? 1u : 0u) : 1u) << wi;
+                    validp |= 1u << wi;
+                }
             }
         }
     }
+    validp |= valid[0];
 
     const long long Rb = (long long)b * out_rows - out_row_origin;    // absolute row of the buffer = Rb + i
     const unsigned nel4 = (unsigned)nel & 3u;
@@ -1367,20 +1400,33 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
         const bool wd = dist != nullptr, wm = dmask != nullptr;
         const char* xi_row = reinterpret_cast<const char*>(sxi + il * A);
         const run16 rund(rd), runm(rm);
+        const bool skip_tail = merge && il + 1 < in;
 #pragma unroll
         for (int u = 0; u < T::SPL; ++u) {
             float* od = rd + so[u];
             uint8_t* om = rm + so[u];
+            constexpr bool HEAD = ACT == 1;
+            const bool head = HEAD && u == 0;
+            const uint32_t vrow = (head && il > 0) ? validp : valid[u];     // (uniform choice)
+#define PS_RP_SLOT(PH_, H_) rowphase_slot<ACT, EXACT, PH_, H_>(xi_row, col[u], aoff[u], cm[u], vrow, od, om, wd, wm, rund, runm, (unsigned)so[u], xim_off, skip_tail)
             if constexpr (!T::PHASED) {
-                rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]);
-            } else {
+                PS_RP_SLOT(0, false);
+            } else if (head) {
                 switch (ph) {   // uniform over the wave
-                    case 0: rowphase_slot<ACT, EXACT, 0>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
-                    case 1: rowphase_slot<ACT, EXACT, 1>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
-                    case 2: rowphase_slot<ACT, EXACT, 2>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
-                    default: rowphase_slot<ACT, EXACT, 3>(xi_row, col[u], aoff[u], cm[u], valid[u], od, om, wd, wm, rund, runm, (unsigned)so[u]); break;
+                    case 0: PS_RP_SLOT(0, HEAD); break;
+                    case 1: PS_RP_SLOT(1, HEAD); break;
+                    case 2: PS_RP_SLOT(2, HEAD); break;
+                    default: PS_RP_SLOT(3, HEAD); break;
+                }
+            } else {
+                switch (ph) {
+                    case 0: PS_RP_SLOT(0, false); break;
+                    case 1: PS_RP_SLOT(1, false); break;
+                    case 2: PS_RP_SLOT(2, false); break;
+                    default: PS_RP_SLOT(3, false); break;
                 }
             }
+#undef PS_RP_SLOT
         }
     }
 }
@@ -1600,11 +1646,12 @@ int launch_rowtile(const K1Cfg& g, const float* xyz, const uint8_t* amask, float
 bool flatA_has(int A);
 
 bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int N, int A) {
-    if (g.variant != 0 || g.flat != 1 || g.rowphase == 2) return false;
+    const int mode = g.rowphase & 15;     // (bits 4..: A/B switches, see launch_rowphase)
+    if (g.variant != 0 || g.flat != 1 || mode == 2) return false;
     if (A < 1 || A > 64 || A == 4 || A == 8) return false;
-    if (A == 15 && g.rowphase != 1 && N >= 16) return false;           // A = 15 has its own kernels from N = 16 on; batches of
+    if (A == 15 && mode != 1 && N >= 16) return false;                 // A = 15 has its own kernels from N = 16 on; batches of
                                                                        // shorter peptides take this kernel (1-D grid: any B)
-    if (A != 15 && flatA_has(A) && g.rowphase != 1) return false;      // even counts with a fixed-A flat kernel
+    if (A != 15 && flatA_has(A) && mode != 1) return false;           // even counts with a fixed-A flat kernel
     if (N < 1 || (long long)N * A * A > (1ll << 28)) return false;   // slot and element indices of a row stay 32-bit
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
@@ -1636,17 +1683,19 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
     const int maxres = rowphase_maxres(A);
-    const size_t lds = (size_t)IR * A * sizeof(float4) + (size_t)maxres * sizeof(typename T::bits_t) +
+    const size_t lds = (size_t)(IR * A + (ACT == 1 ? 1 : 0)) * sizeof(float4) + (size_t)maxres * sizeof(typename T::bits_t) +
                        (size_t)maxres * A * 3 * sizeof(float);
+    const int flags = g.rowphase >> 4;    // [diagnostic] A/B switches of the row-phase kernel (bit 0: A = 1 seam slots written
+                                          // element-wise from both rows, as in round 3)
     const int tp = ACT > 0 ? ACT : A;     // what the plan prints: the atom count
     const char* name = ACT > 0 ? "k1_pairdist_rowphase" : (ACT == 0 ? "k1_pairdist_rowphase_rt_even" : "k1_pairdist_rowphase_rt_odd");
     if (g.exact_sqrt)
         return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, true>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
                      amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
-                     lpg_log2, remap);
+                     lpg_log2, remap, flags);
     return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, false>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
                  amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
-                 lpg_log2, remap);
+                 lpg_log2, remap, flags);
 }
 
 // Fixed-A flat pattern kernels: the EVEN atom counts 14 (atom14), 16, 24, 32, where their line-aligned chunks make them
@@ -1698,7 +1747,7 @@ bool cfg_valid(const K1Cfg& g) {
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
     if (g.jt != 0 && g.jt != 16 && g.jt != 32 && g.jt != 64 && g.jt != 128) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
-    if (g.rowphase < 0 || g.rowphase > 2) return false;
+    if (g.rowphase < 0 || (g.rowphase & 15) > 2 || g.rowphase >= 256) return false;
 #ifdef PS_EXPERIMENTS
     if (g.experiment < 0 || (g.experiment & 15) > 2 || g.experiment > 31) return false;
 #else

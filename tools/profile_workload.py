@@ -8,6 +8,8 @@
     k1      the headline K1 launch (B=64, N=512, A=15)
     k1s     K1 at the small atom counts, ~4 GB of output each: (A, N) = (5, 512), (5, 500), (5, 501), (3, 501), (1, 512),
             (2, 512) through the default dispatch (row-phase kernel)
+    k1u     K1 at the unaligned shapes (A, N) = (5, 501), (1, 501), (37, 100) and the aligned (5, 512), ~4 GB each, three
+            modes per shape in this order: both planes, distance plane only, mask plane only (read with `pmcseq`)
     k5      K5 / K6 / K4 at BASELINE config 5's shape (B=256, N=384): diffuse_xyz (in-kernel Philox), diffuse_xyz with
             injected noise, standardize, backbone_orientations, the fused diffuse + frames step
 Every kernel is launched `reps` times (default 10) after 2 warm-ups, nothing else runs on the GPU."""
@@ -80,6 +82,17 @@ elif what == "k1s":
         m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
         print("k1s", A, N, B, _lib.k1_plan(B, N, A), flush=True)
         repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
+        del xyz, mask, d, m
+elif what == "k1u":
+    for A, N in ((5, 501), (1, 501), (37, 100), (5, 512)):
+        B = max(1, int(4e9 / (N * N * A * A * 5)))
+        xyz, mask = synth(B, N, A)
+        d = torch.empty(B, N, N, A, A, device="cuda")
+        m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+        print("k1u", A, N, B, _lib.k1_plan(B, N, A), f"{2 + reps} dispatches per mode: both, dist only, mask only", flush=True)
+        repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
+        repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, want_mask=False))
+        repeat(lambda: ops.pairwise_distance(xyz, mask, out_mask=m, want_dist=False))
         del xyz, mask, d, m
 elif what == "k1":
     xyz, mask = synth(64, 512)

@@ -3,6 +3,7 @@
 
     python3 tools/summarize_rocprof.py stats <dir> <out.csv>      # *_kernel_stats.csv of a --kernel-trace --stats run
     python3 tools/summarize_rocprof.py pmc <dir> <out.json> [skip] # *_counter_collection.csv of a --pmc run
+    python3 tools/summarize_rocprof.py pmcseq <dir> <out.json> <kernel substring>   # the same, one entry per DISPATCH, in order
 
 `pmc` sums every counter over the dispatches of each kernel (after dropping the first `skip` dispatches of each
 kernel: warm-ups; default 2), and reports per-kernel per-dispatch means.  Counter units are left as rocprofv3 reports
@@ -62,6 +63,22 @@ def pmc(d, out, skip=2):
         json.dump(res, fh, indent=1, sort_keys=True)
 
 
+def pmcseq(d, out, kernel_substr):
+    """Counters of every dispatch whose kernel name contains `kernel_substr`, in dispatch order (for workloads that launch one
+    kernel shape in several modes, which `pmc` would merge)."""
+    disp = {}
+    for f in find(d, "counter_collection.csv"):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if kernel_substr not in r["Kernel_Name"]:
+                    continue
+                dd = disp.setdefault(int(r["Dispatch_Id"]), {"kernel": short(r["Kernel_Name"]), "grid": int(r["Grid_Size"]),
+                                                              "ns_under_pmc": int(r["End_Timestamp"]) - int(r["Start_Timestamp"])})
+                dd[r["Counter_Name"]] = dd.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    with open(out, "w") as fh:
+        json.dump([dict(dispatch=i, **disp[i]) for i in sorted(disp)], fh, indent=1)
+
+
 def trace(d, out, kernel_substr, last_k):
     """Per-dispatch durations of the kernels whose name contains `kernel_substr`, from *_kernel_trace.csv."""
     rows = []
@@ -84,5 +101,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]))
+    elif sys.argv[1] == "pmcseq":
+        pmcseq(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 2)
