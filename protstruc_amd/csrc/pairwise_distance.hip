@@ -1214,7 +1214,9 @@ struct RowPhase {
 };
 
 // column residues a tile's elements can touch (host and device use the same formula for the LDS carve)
-__host__ __device__ inline int rowphase_maxres(int A) { return (4 * 512 + 2) / (A * A) + 2; }
+// -- never more than the chain has: a CA trace of 125 residues stages 2 KB, not the 33 KB of a full tile, and LDS stops
+// being what caps the resident workgroups of short chains
+__host__ __device__ inline int rowphase_maxres(int A, int N) { return min((4 * 512 + 2) / (A * A) + 2, N); }
 
 // One slot of one row.  `xi_row`: LDS address of the row residue's atoms (uniform over the wave); od / om point at the slot
 // (float / byte offset 4 s - ph of the row run), rund / runm + `so` address the same slot the buffer way (uniform row base
@@ -1273,13 +1275,14 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                                                             float* __restrict__ dist, uint8_t* __restrict__ dmask,
                                                             int N, int A_rt, int row_begin, int row_end, int out_rows,
                                                             int out_row_origin, int IR, int n_tiles, int spt,
-                                                            int n_ichunks, int lpg_log2, int xcd_remap, int flags) {
+                                                            int n_ichunks, int lpg_log2, int xcd_remap, int flags,
+                                                            unsigned rcpAA, unsigned rcpA) {
     using T = RowPhase<ACT>;
     typedef typename T::bits_t bits_t;
     constexpr int W = T::W;
     const int A = ACT > 0 ? ACT : A_rt;                                 // a constant wherever ACT > 0
     const int AA = A * A;
-    const int maxres = rowphase_maxres(A);
+    const int maxres = rowphase_maxres(A, N);
     extern __shared__ __attribute__((aligned(16))) char smem_rp[];
     float4* sxi = reinterpret_cast<float4*>(smem_rp) + (ACT == 1 ? 1 : 0);   // [IR * A] row atoms: x, y, z, mask bit (A = 1: one
                                                                         // atom of padding in front, "row -1" of the seam logic)
@@ -1366,8 +1369,19 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
                 const int t = 4 * s - T::W0 + wi;
                 const bool ok = s < s1 && t >= 0 && t < nel;
                 const unsigned e = ok ? (unsigned)t : (unsigned)t_lo;
-                const unsigned j = e / (unsigned)AA, r = e - j * (unsigned)AA;      // constant divisors when ACT > 0
-                const unsigned a = r / (unsigned)A, c = r - a * (unsigned)A;
+                // constant divisors when ACT > 0; the run-time instantiations multiply by floor(2^32 / d) and correct once
+                // (e < 2^28: the estimate is the quotient or one less) -- 28 run-time divisions per lane were ~15 % of a
+                // workgroup's instructions
+                unsigned j, r, a, c;
+                if (ACT > 0) {
+                    j = e / (unsigned)AA, r = e - j * (unsigned)AA;
+                    a = r / (unsigned)A, c = r - a * (unsigned)A;
+                } else {
+                    j = __umulhi(e, rcpAA), r = e - j * (unsigned)AA;
+                    if (r >= (unsigned)AA) ++j, r -= (unsigned)AA;
+                    a = __umulhi(r, rcpA), c = r - a * (unsigned)A;
+                    if (c >= (unsigned)A) ++a, c -= (unsigned)A;
+                }
                 const float* p = sxj + ((j - (unsigned)j_lo) * A + c) * 3;
                 col[u][wi][0] = p[0];
                 col[u][wi][1] = p[1];
@@ -1671,9 +1685,11 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     // decode -- wants to be amortised.  Same-process sweeps of 4 .. 32 rows on two boxes (profiles/
     // r03_k1_ab_rowphase_tiling.log, r03_k1_rowphase_rows_per_lane.log): the compile-time counts (cheap decode) peak at
     // 8-16 rows (A = 5, N = 501: 5.6-6.3 TB/s against 3.7-5.2 with 32), A = 1 / 2, whose rows are short, at 16-24; the
-    // run-time even counts at 8-16; the run-time odd counts (seven-element windows, run-time divisions) at 32.
+    // run-time even counts at 8-16; the run-time odd counts (seven-element windows) wanted 32 while their index decode
+    // divided at run time, and 16-24 since it multiplies by reciprocals (round 4, profiles/r04_k1_rowphase_rows_runtime_odd.log:
+    // A = 17 / 27 at N = 125 6.33 / 6.37 TB/s with 16 rows against 5.93 / 6.09 with 32; A = 35, 63: 24 rows).
     // cfg.rows_per_block > 1 overrides (A/B runs).
-    const int rpl = g.rows_per_block > 1 ? g.rows_per_block : (ACT > 0 ? (ACT <= 2 ? 16 : 12) : (ACT == 0 ? 12 : 32));
+    const int rpl = g.rows_per_block > 1 ? g.rows_per_block : (ACT > 0 ? (ACT <= 2 ? 16 : 12) : (ACT == 0 ? 12 : (A < 32 ? 16 : 24)));
     const int n_ichunks = (rows + rpl * G - 1) / (rpl * G), IR = (rows + n_ichunks - 1) / n_ichunks;   // <= rpl * G rows, balanced
     // Tiles: FULL tiles of tile_slots and a short last one.  (Balanced tiles leave the last wave of EVERY workgroup idle
     // for a pass: A = 5, N = 500 ran 4.4 against 5.2 TB/s.)
@@ -1682,20 +1698,21 @@ int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, floa
     const unsigned long long n_wg = (unsigned long long)n_tiles * n_ichunks * B;
     if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int remap = (g.xcd_remap && n_wg >= 64) ? 1 : 0;
-    const int maxres = rowphase_maxres(A);
+    const int maxres = rowphase_maxres(A, N);
     const size_t lds = (size_t)(IR * A + (ACT == 1 ? 1 : 0)) * sizeof(float4) + (size_t)maxres * sizeof(typename T::bits_t) +
                        (size_t)maxres * A * 3 * sizeof(float);
     const int flags = g.rowphase >> 4;    // [diagnostic] A/B switches of the row-phase kernel (bit 0: A = 1 seam slots written
                                           // element-wise from both rows, as in round 3)
+    const unsigned rcpAA = (unsigned)((1ull << 32) / (unsigned)(A * A)), rcpA = (unsigned)((1ull << 32) / (unsigned)A);   // (A = 1: unused)
     const int tp = ACT > 0 ? ACT : A;     // what the plan prints: the atom count
     const char* name = ACT > 0 ? "k1_pairdist_rowphase" : (ACT == 0 ? "k1_pairdist_rowphase_rt_even" : "k1_pairdist_rowphase_rt_odd");
     if (g.exact_sqrt)
         return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, true>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
                      amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
-                     lpg_log2, remap, flags);
+                     lpg_log2, remap, flags, rcpAA, rcpA);
     return k1_go(go, "rowphase", name, tp, k1_pairdist_rowphase<ACT, false>, dim3((unsigned)n_wg), dim3(256), lds, xyz,
                  amask, dist, dmask, N, A, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, spt, n_ichunks,
-                 lpg_log2, remap, flags);
+                 lpg_log2, remap, flags, rcpAA, rcpA);
 }
 
 // Fixed-A flat pattern kernels: the EVEN atom counts 14 (atom14), 16, 24, 32, where their line-aligned chunks make them
