@@ -1445,6 +1445,92 @@ __global__ __launch_bounds__(256) void k1_pairdist_rowphase(const float* __restr
     }
 }
 
+// ---- A = 1, short chains (CA traces of peptides and small proteins, in large batches) ----
+// The row-phase kernel keeps everything per row in scalar registers and gives a wave one row at a time: fine for 2 KB rows
+// (N = 512), but a 64-residue trace is a 256-byte row -- 16 of a wave's 128 lane-slots -- and the per-row scalar work
+// dominates (N = 64: 2.3 TB/s, N = 32: 0.9, N = 16: 0.3; profiles/r04_k1_n_sweep_a1.log).  Here the (B, N, N) output is
+// ONE flat run of 16-byte slots; a workgroup owns CS consecutive slots (whatever structures they belong to), stages the
+// atoms of those structures in LDS (x, y, z, mask bit per atom) and every lane decodes its slot's first element into
+// (structure, i, j) with two reciprocal multiplications, steps through the other three by increment-and-wrap, and gathers
+// both atoms of every element from LDS.  ~2x the vector work per slot of the row-phase kernel, but every lane of every
+// store instruction is live whatever N is.  Same formula and operand order as every other K1 kernel: same bits.
+// Full matrices only (row_begin = 0, row_end = out_rows = N): row-sharded launches keep the row-phase kernel.
+constexpr int CA_K = 8;                  // slots per lane
+constexpr int CA_CS = 256 * CA_K;        // slots per workgroup: 32 KB of distances + 8 KB of mask
+
+__host__ __device__ inline int ca_max_structs(int N) { return (4 * CA_CS + N * N - 1) / (N * N) + 1; }
+
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k1_pairdist_ca_flat(const float* __restrict__ xyz, const uint8_t* __restrict__ amask,
+                                                           float* __restrict__ dist, uint8_t* __restrict__ dmask, int B,
+                                                           int N, unsigned rcpNN, unsigned rcpN) {
+    extern __shared__ __attribute__((aligned(16))) char smem_ca[];
+    float4* sat = reinterpret_cast<float4*>(smem_ca);                   // [structures of this workgroup][N]
+    const int tid = threadIdx.x;
+    const unsigned NN = (unsigned)N * (unsigned)N;
+    const unsigned long long total = (unsigned long long)B * NN;        // elements of the whole output
+    const unsigned long long e_lo = (unsigned long long)blockIdx.x * (4ull * CA_CS);
+    const unsigned long long e_hi = min(e_lo + 4ull * CA_CS, total);
+    const unsigned b_lo = (unsigned)(e_lo / NN), b_hi = (unsigned)((e_hi - 1) / NN);
+    const unsigned n_at = (b_hi - b_lo + 1u) * (unsigned)N;             // atoms to stage: one contiguous range of xyz
+    {
+        const float* g = xyz + (size_t)b_lo * N * 3;
+        float* l = reinterpret_cast<float*>(sat);
+        for (unsigned f = tid; f < n_at * 3u; f += 256u) {
+            const unsigned at = f / 3u, comp = f - at * 3u;
+            l[at * 4u + comp] = g[f];
+        }
+        const uint8_t* gm = amask ? amask + (size_t)b_lo * N : nullptr;
+        for (unsigned at = tid; at < n_at; at += 256u)
+            reinterpret_cast<uint32_t*>(sat)[at * 4u + 3u] = gm ? (gm[at] != 0 ? 1u : 0u) : 1u;
+    }
+    __syncthreads();
+    const unsigned rel0 = (unsigned)(e_lo - (unsigned long long)b_lo * NN);   // < N * N
+    const run16 rund(dist + e_lo), runm(dmask + e_lo);                  // (only used when the plane is requested)
+    const bool wd = dist != nullptr, wm = dmask != nullptr;
+    const char* base = reinterpret_cast<const char*>(sat);
+#pragma unroll 2
+    for (int k = 0; k < CA_K; ++k) {
+        const unsigned sl = (unsigned)k * 256u + (unsigned)tid;         // slot within the workgroup's run
+        const unsigned long long e0 = e_lo + 4ull * sl;
+        if (e0 >= e_hi) break;
+        // first element: rel = element index relative to structure b_lo (< 4 CS + N N: 32 bits)
+        const unsigned rel = rel0 + 4u * sl;
+        unsigned bl = __umulhi(rel, rcpNN), r = rel - bl * NN;
+        if (r >= NN) ++bl, r -= NN;
+        unsigned i = __umulhi(r, rcpN), j = r - i * (unsigned)N;
+        if (j >= (unsigned)N) ++i, j -= (unsigned)N;
+        unsigned row = (bl * (unsigned)N + i) * 16u, col = (bl * (unsigned)N + j) * 16u;   // LDS byte offsets of the two atoms
+        const unsigned row_end = (bl * (unsigned)N + (unsigned)N) * 16u;                  // one past the structure's last atom
+        float v[4];
+        uint32_t mw = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xi = *reinterpret_cast<const float4*>(base + row);
+            const float4 xj = *reinterpret_cast<const float4*>(base + col);
+            v[q] = dist_pp<EXACT>(xi, make_float4(xj.x, xj.y, xj.z, 0.f));
+            mw |= (__float_as_uint(xi.w) & __float_as_uint(xj.w)) << (8 * q);
+            // next element: j + 1; past the row's end -> next row, j = 0; past the structure's last row -> next structure
+            col += 16u;
+            if (col == row_end) {
+                row += 16u;
+                col = row_end - (unsigned)N * 16u;
+                if (row == row_end) col = row_end;       // (row, col) = first atom of the next structure; its row_end is not
+            }                                            // needed: a slot holds 4 elements and N * N >= 4 (N >= 8)
+        }
+        if (e0 + 4ull <= e_hi) {
+            if (wd) rund.store(16u * sl, 0u, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                        __float_as_uint(v[3])));
+            if (wm) runm.store4(4u * sl, 0u, mw);
+        } else {   // the last slot of the whole output (B * N * N is not a multiple of 4)
+            for (int q = 0; q < (int)(e_hi - e0); ++q) {
+                if (wd) dist[e0 + q] = v[q];
+                if (wm) dmask[e0 + q] = (uint8_t)((mw >> (8 * q)) & 1u);
+            }
+        }
+    }
+}
+
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
@@ -1670,6 +1756,20 @@ bool rowphase_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, 
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
+// CA traces (A = 1) of 8 .. CA_FLAT_MAX_N residues, full matrices: the flat kernel (see k1_pairdist_ca_flat).  cfg.rowphase = 1
+// keeps the row-phase kernel (A/B runs).  The crossover (profiles/r04_k1_n_sweep_a1.log, same box, TB/s flat / row-phase):
+// N = 64 5.74 / 2.25, 128 5.87 / 3.74, 200 5.54 / 4.84, 255 5.53 / 4.63; second box 256 5.72 / 6.12, 300 4.98 / 5.48,
+// 512 4.75 / 6.75 -- the flat kernel stages whole structures per 8192 elements, which stops paying once a structure is
+// longer than that.
+constexpr int CA_FLAT_MAX_N = 255;
+bool ca_flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int row_begin, int row_end,
+                      int out_rows, int out_row_origin) {
+    if (A != 1 || g.variant != 0 || g.flat != 1 || (g.rowphase & 15) != 0) return false;
+    if (N < 8 || N > CA_FLAT_MAX_N) return false;
+    if (row_begin != 0 || row_end != N || out_rows != N || out_row_origin != 0) return false;
+    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
 template <int ACT>
 int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                     int A, int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
@@ -1810,6 +1910,18 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
         if (A == 4)
             return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
         return launch_rowtile<8>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);
+    }
+    if (ca_flat_eligible(g, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin)) {
+        const unsigned long long total = (unsigned long long)B * N * N;
+        const unsigned long long n_wg = (total + 4ull * CA_CS - 1) / (4ull * CA_CS);
+        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        const size_t lds = (size_t)ca_max_structs(N) * N * sizeof(float4);
+        const unsigned rcpNN = (unsigned)((1ull << 32) / (unsigned)(N * N)), rcpN = (unsigned)((1ull << 32) / (unsigned)N);
+        if (g.exact_sqrt)
+            return k1_go(go, "ca_flat", "k1_pairdist_ca_flat", -1, k1_pairdist_ca_flat<true>, dim3((unsigned)n_wg), dim3(256), lds,
+                         xyz, atom_mask, dist, dist_mask, B, N, rcpNN, rcpN);
+        return k1_go(go, "ca_flat", "k1_pairdist_ca_flat", -1, k1_pairdist_ca_flat<false>, dim3((unsigned)n_wg), dim3(256), lds,
+                     xyz, atom_mask, dist, dist_mask, B, N, rcpNN, rcpN);
     }
     if (rowphase_eligible(g, dist, dist_mask, N, A)) {
 #define PS_K1_RP(A_) case A_: return launch_rowphase<A_>(g, xyz, atom_mask, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin, go);

@@ -30,7 +30,9 @@ FAMILY_SHAPES = [
     (2, 40, 4, None, False, {}, "rowtile"),
     (2, 33, 8, (1, 32), False, {}, "rowtile"),
     # row-phase kernel (round 3): every other atom count up to 13, any length
-    (3, 33, 1, None, False, {}, "rowphase"),
+    (3, 501, 1, None, False, {}, "rowphase"),
+    (3, 33, 1, (2, 30), False, {}, "rowphase"),
+    (4, 100, 1, None, False, {"k1_rowphase": 1}, "rowphase"),
     (2, 18, 2, None, False, {}, "rowphase"),
     (2, 21, 5, (4, 20), True, {}, "rowphase"),
     (2, 40, 7, None, False, {}, "rowphase"),
@@ -44,10 +46,14 @@ FAMILY_SHAPES = [
     (2, 33, 14, None, False, {"k1_rowphase": 1}, "rowphase"),
     (1, 20, 37, (3, 17), False, {}, "rowphase"),
     (2, 33, 25, None, False, {}, "rowphase"),
+    # CA traces (A = 1) of 8 .. 255 residues, full matrices (round 4): the flat kernel
+    (3, 33, 1, None, False, {}, "ca_flat"),
+    (40, 9, 1, None, False, {}, "ca_flat"),
+    (2, 255, 1, None, False, {}, "ca_flat"),
     # element-per-lane kernel: A > 64, or nothing else eligible (N < 16 without the row-phase kernel; the simple variant)
     (1, 8, 70, None, False, {}, "element"),
     (2, 10, 20, None, False, {"k1_rowphase": 2}, "element"),
     (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
 ]
 
-ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "element"}
+ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "ca_flat", "element"}

@@ -396,6 +396,10 @@ def test_k1_any_atom_count_kernel_matches_element_kernel(SB, exact):
              (2, 500, 1), (2, 501, 1), (2, 502, 1), (2, 503, 1), (1, 2100, 1), (3, 5, 1), (2, 1, 1), (1, 1030, 2),
              (2, 2, 2), (2, 99, 2), (2, 100, 6), (2, 37, 7), (2, 3, 7), (1, 64, 9), (2, 50, 10), (2, 33, 11), (1, 40, 12),
              (2, 29, 13), (1, 90, 5), (1, 91, 5), (1, 93, 3), (1, 94, 3),
+             # CA traces of 8 .. 255 residues (round 4: the flat A = 1 kernel): many structures per workgroup, a workgroup
+             # boundary inside a structure, a last slot that is not full (B * N * N % 4 != 0), both ends of the range
+             (3, 8, 1), (3, 9, 1), (700, 11, 1), (5, 16, 1), (37, 37, 1), (3, 64, 1), (2, 100, 1), (1, 129, 1), (2, 255, 1),
+             (1, 256, 1),
              # the fixed-A flat pattern kernels added in round 3
              (2, 40, 24), (1, 33, 27), (1, 30, 32),
              # atom counts served by the run-time instantiations of the row-phase kernel (even / odd), short and long rows

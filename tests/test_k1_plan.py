@@ -45,6 +45,7 @@ def test_plan_headline_and_config_shapes():
         assert p["n_workgroups"] == B * n_rows * (N // 32)
     assert _lib.k1_plan(64, 500, 15, device=0)["family"] == "flat"
     assert _lib.k1_plan(8, 512, 1, device=0)["family"] == "rowphase"          # a CA trace
+    assert _lib.k1_plan(8, 128, 1, device=0)["family"] == "ca_flat"           # a short one
     assert _lib.k1_plan(0, 512, 15, device=0)["family"] == "empty"
 
 
