@@ -76,7 +76,7 @@ typedef struct ps_k1_config {
                              pattern kernel (A = 14, 15, 16, 24, 32) and no row-tile / row-phase kernel.  (3 was the any-A
                              flat kernel of rounds 1-2, removed: the row-phase kernel is faster at every atom count) */
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1, which for chains shorter than 64
-                             residues means ceil(64 / N) rows); row-phase kernel: rows per lane when > 1 (default: 12 / 16 / 32
+                             residues means ceil(64 / N) rows); row-phase kernel: rows per lane when > 1 (default: 12 / 16 / 24
                              by atom count); row-tile kernel: rows per workgroup when > 1 (default 6) */
     int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 20) */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
@@ -87,8 +87,9 @@ typedef struct ps_k1_config {
     int store_nt;         /* [diagnostic] 1: non-temporal stores (slower on MI355X; kept for A/B runs) */
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
     int rowphase;         /* [diagnostic] row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
-                             dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel; 1 also for A = 14, 15, 16,
-                             24, 32 (A/B runs); 2 never (fixed-A flat / element kernels instead).  Bits 4..7 (value / 16) are A/B
+                             dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel, short CA traces (A = 1, 8..255
+                             residues, full matrices) excepted: they take the flat CA kernel; 1 also for A = 14, 15, 16, 24, 32 and
+                             for those CA traces (A/B runs); 2 never (fixed-A flat / element kernels instead).  Bits 4..7 (value / 16) are A/B
                              switches of that kernel: 16 = the A = 1 seam slots written element-wise from both rows (round 3) */
     int experiment;       /* [diagnostic] must be 0 in the product library; timing experiments exist only in builds made with
                              -DPS_EXPERIMENTS (tools/), where 1 = first correctly rounded sqrt routine, 2 = store-only
@@ -150,7 +151,7 @@ typedef struct ps_k1_plan {
     int struct_size;            /* in: sizeof(ps_k1_plan) */
     int n_launches;             /* 0 (empty input) or 1 (every kernel writes both planes in one launch) */
     char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" |
-                                   "element" (other atom counts); "empty"; a second launch would be appended with " + " */
+                                   "ca_flat" | "element" (other atom counts); "empty"; a second launch would be appended with " + " */
     char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<32>" */
     unsigned n_workgroups;      /* grid of the first launch */
     unsigned lds_bytes;         /* static + dynamic LDS per workgroup of the first launch */
