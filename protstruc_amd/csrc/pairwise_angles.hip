@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <initializer_list>
 #include <type_traits>
 
@@ -427,56 +428,87 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
     }
 }
 
-// The featuriser on the skeleton of k3_sweep (round 4): one 1024-thread workgroup per CU, the row residues' N / CA / CB
-// points and their three mask bits staged once per segment in LDS (pair-interleaved), tasks of CH rows x 64 * NC columns
-// pulled from an LDS counter, NC = 2 or 4 consecutive column residues per lane -- every float plane goes out in 4 * NC-byte
-// stores and every mask plane in one NC-byte store per row, write-through -- and the two dihedrals' and the planar angle's
-// chains interleaved across the columns.  Same arithmetic per pair as k3_inter_residue_geometry above: same bits.
-template <bool EXACT, int NC, bool M16>
+// The featuriser on the skeleton of k3_sweep (round 4): one workgroup per CU (1024 threads at NC = 2, 512 at NC = 4), the row
+// residues' N / CA / CB points and their three mask bits staged in LDS (pair-interleaved), tasks pulled from an LDS
+// counter, and the two dihedrals' and the planar angle's chains interleaved across the NC columns of a lane.  Same
+// arithmetic per pair as k3_inter_residue_geometry above: same bits.
+//   * Small tasks, in memory order.  The column points (CA, O, CB: staged once per structure, 36 bytes per residue) come from
+//     LDS per task and strip.  The first cut gave a workgroup one (structure, strip) segment at a time, 8-row tasks and the
+//     column points in registers for the whole segment.  That is only good when a workgroup's share divides into whole
+//     segments (B = 128, N = 512: half a structure each): the waves of a workgroup wait for each other at every segment
+//     boundary for up to one task, and a share cut into a short and a long segment (any other B, N) idled them for a fifth
+//     of the time; and its staging loops walked ~13 dependent round trips to L2 per segment (an element per thread; now a
+//     residue per thread with its nine loads in flight: N = 512 178 -> 168 us).  N = 500 284 us, N = 510 415, N = 200 344
+//     against 211 at N = 512, 2^25 pairs each (profiles/r04_k3_featuriser_shapes.log).
+//   * VEC: the lane's NC columns are consecutive and every float plane goes out in 4 * NC-byte stores (N % NC == 0, planes
+//     4 * NC-byte aligned).  !VEC (any N, any 4-byte alignment): the columns are 64 apart and a store instruction writes 64
+//     consecutive floats of a row, as in k3_sweep.
+//   * M16 (VEC, NC = 4, N % 16 == 0, 16-byte aligned mask planes): the mask planes have their own lane map inside a strip:
+//     a lane owns 16 consecutive column residues of one row, a store instruction carries four rows x 256 bytes.
+//     !M16: the mask planes are written FLAT.  The mask bytes of a task's rows are one contiguous run of every plane
+//     (rows are contiguous in memory), whatever N is; the run is cut on the plane's absolute 16-byte grid -- a group that
+//     starts in the task's rows belongs to the task, also where it runs into the next task's first row -- and a lane
+//     builds 16 bytes at a time from bit sets: 16 bits of the structure's column mask (two LDS words, one v_alignbit) AND
+//     the row's bit, the next row's where the group wraps, spread to bytes: a store instruction writes 1 KB.  The task of every
+//     fourth chunk's first strip writes the masks of 16 rows (full lanes, one set-up).  Only at a structure's two ends are
+//     the bytes outside whole groups written as bytes.
+//   * WT: write-through stores (sc1) where every store covers whole 128-byte lines (N % 32 == 0); write-back otherwise,
+//     so that lines shared by two stores merge in L2 instead of going out as two partial writes.
+template <bool EXACT, int NC, bool VEC, bool M16, bool WT>
 __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg) {
+    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
-    static_assert(!M16 || NC == 4, "16-byte mask stores ride on the four-column kernel");
-    typedef typename std::conditional<NC == 4, uint32_t, uint16_t>::type mvec;
-    constexpr int POL = 16;                       // sc1: write-through
-    extern __shared__ __attribute__((aligned(16))) f32x2 k3_rowbuf[];   // [row pair][N, CA, CB][xyz]; the row mask words follow, then (M16) the strip's column mask bytes
+    static_assert(!M16 || (NC == 4 && VEC), "16-byte strip mask stores ride on the four-column vector kernel");
+    constexpr int POL = WT ? 16 : 0;
+    extern __shared__ __attribute__((aligned(16))) f32x2 k3_rowbuf[];   // [row pair][N, CA, CB][xyz]; then the row mask words, the column points, the column masks
     __shared__ unsigned next_task;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_waves = (int)(blockDim.x >> 6);
     const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
     if (t0 >= t1) return;                         // whole workgroup
-    const int max_pairs = (N + 2) / 2;
+    const int max_pairs = (N + 2) / 2, Np = (N + 3) & ~3;
     uint32_t* rowmask = reinterpret_cast<uint32_t*>(k3_rowbuf + (size_t)max_pairs * 9);   // per row pair: byte 0 = row 2r, byte 1 = row 2r + 1; bits n = 1, ca = 2, cb = 4
-    // M16: the mask planes get their OWN lane map -- a lane owns 16 consecutive column residues of one row, a store
-    // instruction carries four rows x 256 bytes (1 KB instead of the 256 B of the dword form: the mask planes are bound by
-    // the rate of store instructions, not by bytes).  colmask[plane][column of the strip], planes CA, CB, O.
-    uint8_t* colmask = reinterpret_cast<uint8_t*>(k3_rowbuf) + (((size_t)max_pairs * (9 * 8 + 4) + 15) & ~(size_t)15);   // 16-byte aligned
+    float* colpts = reinterpret_cast<float*>(reinterpret_cast<char*>(k3_rowbuf) + (((size_t)max_pairs * (9 * 8 + 4) + 32 + 15) & ~(size_t)15));   // [CA, O, CB][xyz][Np] (the row mask words have 8 spare)
+    // M16: colmask[plane][column] as bytes; !M16: colbits[plane][word] = the column masks as bit sets (planes CA, CB, O;
+    // zero beyond N and two zero words of padding).  Same region, 16-byte aligned.
+    uint8_t* colmask = reinterpret_cast<uint8_t*>(colpts + 9 * Np);
+    uint32_t* colbits = reinterpret_cast<uint32_t*>(colmask);
+    const int nw = (N + 31) / 32 + 2;
+    const int row_bytes = N * 4;
     int staged_b = -1, staged_lo = -1, staged_hi = -1;
-    for (unsigned g = t0 / (unsigned)n_chunks; g <= (t1 - 1u) / (unsigned)n_chunks; ++g) {   // g = b * n_strips + strip
-        const int c_lo = (int)(max(t0, g * (unsigned)n_chunks) - g * (unsigned)n_chunks);
-        const int c_hi = (int)(min(t1, (g + 1u) * (unsigned)n_chunks) - g * (unsigned)n_chunks);
-        const int b = (int)(g / (unsigned)n_strips), strip = (int)(g % (unsigned)n_strips);
-        const int r_lo = c_lo * CH, r_hi = min(c_hi * CH, N);
+    // tasks of one structure: (chunk of CH rows, strip), a chunk's strips adjacent.  (Tried: a chunk of two rows x ALL strips,
+    // the wave walking the strips inside the row pair, so that every 64-byte segment two stores share -- a row's strips, a
+    // row's end and the next row's start -- is completed by one wave within a trip: 2.2 % of the write requests at N = 500 are
+    // 32-byte partials, none at N = 496 whose rows are whole segments, profiles/r04_featuriser_pmc.log.  It was 3-7 %
+    // SLOWER, N = 500 267 against 259 us: the column points then come from LDS every trip.)
+    const int tpc = n_strips;                                         // tasks per chunk
+    const unsigned n_sub = (unsigned)n_chunks * (unsigned)tpc;
+    for (unsigned b = t0 / n_sub; b <= (t1 - 1u) / n_sub; ++b) {       // the structures of this workgroup's tasks
+        const int c_lo = (int)(max(t0, b * n_sub) - b * n_sub);
+        const int c_hi = (int)(min(t1, (b + 1u) * n_sub) - b * n_sub);
+        const int r_lo = (c_lo / tpc) * CH, r_hi = min(((c_hi - 1) / tpc + 1) * CH, N);
         const float* xb = xyz + (size_t)b * N * (size_t)A * 3;   // uniform
         const uint8_t* mb = amask ? amask + (size_t)b * N * A : nullptr;
-        __syncthreads();                                          // the previous segment's readers are done
-        if (b != staged_b || r_lo != staged_lo || r_hi != staged_hi) {
+        __syncthreads();                                          // the previous structure's readers are done
+        if ((int)b != staged_b || r_lo != staged_lo || r_hi != staged_hi) {
+            // one residue per thread, its nine loads in flight together (an element per thread made every workgroup walk
+            // 9 N / 512 dependent round trips to L2 per structure: ~10 us of a 170 us launch)
             float* rb = reinterpret_cast<float*>(k3_rowbuf);
-            const int n_el = (r_hi - r_lo) * 9;
-            for (int e = (int)threadIdx.x; e < n_el; e += (int)blockDim.x) {
-                const int row = e / 9, rem = e - row * 9, q = rem / 3, c = rem - q * 3;
-                const int at = (q == 2) ? 4 : q;                  // N = 0, CA = 1, CB = 4
-                rb[((((row >> 1) * 3 + q) * 3 + c) << 1) + (row & 1)] = xb[(size_t)(r_lo + row) * (size_t)A * 3 + at * 3 + c];
+            for (int row = (int)threadIdx.x; row < r_hi - r_lo; row += (int)blockDim.x) {
+                const float* pr = xb + (size_t)(r_lo + row) * (size_t)A * 3;
+                const float v[9] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[12], pr[13], pr[14]};   // N, CA, CB
+#pragma unroll
+                for (int qc = 0; qc < 9; ++qc) rb[(((row >> 1) * 9 + qc) << 1) + (row & 1)] = v[qc];
             }
-            const int n_pairs = (r_hi - r_lo + 1) / 2;
+            const int n_pairs = (r_hi - r_lo) / 2 + 1 + (M16 ? 0 : (16 - CH) / 2);   // !M16: up to 16 - CH rows and one beyond the tasks' own (flat mask groups)
             for (int r = (int)threadIdx.x; r < n_pairs; r += (int)blockDim.x) {
                 uint32_t w = 0x0707u;
                 if (mb) {
-                    const int ia = r_lo + 2 * r, ib = min(ia + 1, N - 1);
+                    const int ia = min(r_lo + 2 * r, N - 1), ib = min(ia + 1, N - 1);
                     const uint8_t* pa = mb + (size_t)ia * A;
                     const uint8_t* pb = mb + (size_t)ib * A;
                     w = (pa[0] != 0 ? 1u : 0u) | (pa[1] != 0 ? 2u : 0u) | (pa[4] != 0 ? 4u : 0u) |
@@ -484,147 +516,231 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                 }
                 rowmask[r] = w;
             }
-            staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
         }
-        if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
-        const int j0 = (strip * 64 + lane) * NC;
-        const bool live = j0 < N;                                 // N % NC == 0: a lane's columns are all in or all out
-        const int jc = live ? j0 : N - NC;
-        f3 ca_j[NC], o_j[NC], cb_j[NC];
-        uint32_t mj_ca = 0x01010101u, mj_o = 0x01010101u, mj_cb = 0x01010101u;   // byte c = mask of column jc + c
+        if ((int)b != staged_b) {                                 // the structure's column side: points, masks
+            for (int j = (int)threadIdx.x; j < Np; j += (int)blockDim.x) {
+                const float* pj = xb + (size_t)min(j, N - 1) * (size_t)A * 3;   // (the padding repeats the last residue)
+                const float v[9] = {pj[3], pj[4], pj[5], pj[9], pj[10], pj[11], pj[12], pj[13], pj[14]};   // CA, O, CB
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const float* sj = xb + (size_t)(jc + c) * (size_t)A * 3;
-            ca_j[c] = load3(sj + 3); o_j[c] = load3(sj + 9); cb_j[c] = load3(sj + 12);
-        }
-        if (mb) {
-            mj_ca = mj_o = mj_cb = 0;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const uint8_t* mj = mb + (size_t)(jc + c) * A;
-                mj_ca |= (mj[1] != 0 ? 1u : 0u) << (8 * c);
-                mj_o |= (mj[3] != 0 ? 1u : 0u) << (8 * c);
-                mj_cb |= (mj[4] != 0 ? 1u : 0u) << (8 * c);
+                for (int qc = 0; qc < 9; ++qc) colpts[qc * Np + j] = v[qc];
             }
-        }
-        if constexpr (M16) {
-            for (int t = (int)threadIdx.x; t < 64 * NC; t += (int)blockDim.x) {
-                const int j = strip * 64 * NC + t;
-                uint8_t a = 0, c2 = 0, o = 0;
-                if (j < N) {
-                    a = c2 = o = 1;
+            if constexpr (M16) {
+                for (int j = (int)threadIdx.x; j < N; j += (int)blockDim.x) {
+                    uint8_t a = 1, c2 = 1, o = 1;
                     if (mb) {
                         const uint8_t* mj = mb + (size_t)j * A;
                         a = mj[1] != 0; c2 = mj[4] != 0; o = mj[3] != 0;
                     }
+                    colmask[j] = a; colmask[N + j] = c2; colmask[2 * N + j] = o;
                 }
-                colmask[t] = a; colmask[64 * NC + t] = c2; colmask[2 * 64 * NC + t] = o;
-            }
-        }
-        __syncthreads();
-        k3_u32x4 cm_ca = {0, 0, 0, 0}, cm_cb = {0, 0, 0, 0}, cm_o = {0, 0, 0, 0};
-        const int gq = lane & 15, rq = lane >> 4;                 // M16: this lane's 16-column group and row of a 4-row store
-        const bool glive = strip * 64 * NC + 16 * gq < N;         // N % 16 == 0: a group is in or out
-        if constexpr (M16) {
-            cm_ca = *reinterpret_cast<const k3_u32x4*>(colmask + 16 * gq);
-            cm_cb = *reinterpret_cast<const k3_u32x4*>(colmask + 64 * NC + 16 * gq);
-            cm_o = *reinterpret_cast<const k3_u32x4*>(colmask + 2 * 64 * NC + 16 * gq);
-        }
-        // per plane: the segment's rows as one buffer (uniform base, the lane's constant byte offset, the row's byte offset
-        // as a scalar)
-        const size_t seg = ((size_t)b * N + (size_t)r_lo) * N;
-        auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
-        const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
-                                     r_th = rs(theta + seg), r_ph = rs(phi + seg), r_mca = rs(m_ca + seg), r_mcb = rs(m_cb + seg),
-                                     r_mno = rs(m_no + seg);
-        const int lane_off = j0 * 4, lane_off_m = j0;
-        const int row_bytes = N * 4;
-        auto put = [&](const __amdgpu_buffer_rsrc_t& r, int so, const f32x2 (&v)[NC]) {
-            if constexpr (NC == 4) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), r, lane_off, so, POL);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), r, lane_off, so + row_bytes, POL);
             } else {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), r, lane_off, so, POL);
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), r, lane_off, so + row_bytes, POL);
-            }
-        };
-        auto putm = [&](const __amdgpu_buffer_rsrc_t& r, int so, uint32_t w) {
-            if constexpr (NC == 4)
-                __builtin_amdgcn_raw_buffer_store_b32(w, r, lane_off_m, so, POL);
-            else
-                __builtin_amdgcn_raw_buffer_store_b16((mvec)w, r, lane_off_m, so, POL);
-        };
-        int c = c_lo + wave;
-        while (c < c_hi) {
-            const int i0 = (c - c_lo) * CH;                       // rows relative to r_lo (CH is even: pairs stay aligned)
-            const int i1 = min(i0 + CH, r_hi - r_lo);
-            if constexpr (M16) {                                  // the task's mask planes: four rows per store instruction
-                for (int k4 = i0; k4 < i1; k4 += 4) {
-                    const int rr = k4 + rq;
-                    if (rr < i1 && glive) {
-                        const uint32_t w = rowmask[rr >> 1] >> (8 * (rr & 1));
-                        const int vo = rr * N + strip * 64 * NC + 16 * gq;
-                        const k3_u32x4 z = {0, 0, 0, 0};
-                        __builtin_amdgcn_raw_buffer_store_b128((w & 2u) ? cm_ca : z, r_mca, vo, 0, POL);
-                        __builtin_amdgcn_raw_buffer_store_b128((w & 4u) ? cm_cb : z, r_mcb, vo, 0, POL);
-                        __builtin_amdgcn_raw_buffer_store_b128((w & 1u) ? cm_o : z, r_mno, vo, 0, POL);
+                for (int base = wave * 64; base < nw * 32; base += n_waves * 64) {   // (uniform per wave)
+                    const int j = base + lane;
+                    bool a = false, c2 = false, o = false;
+                    if (j < N) {
+                        a = c2 = o = true;
+                        if (mb) {
+                            const uint8_t* mj = mb + (size_t)j * A;
+                            a = mj[1] != 0; c2 = mj[4] != 0; o = mj[3] != 0;
+                        }
+                    }
+                    const unsigned long long ba = __ballot(a), bc = __ballot(c2), bo = __ballot(o);
+                    if (lane == 0) {
+                        const int k = base >> 5;
+                        colbits[k] = (uint32_t)ba; colbits[nw + k] = (uint32_t)bc; colbits[2 * nw + k] = (uint32_t)bo;
+                        if (k + 1 < nw) {
+                            colbits[k + 1] = (uint32_t)(ba >> 32); colbits[nw + k + 1] = (uint32_t)(bc >> 32);
+                            colbits[2 * nw + k + 1] = (uint32_t)(bo >> 32);
+                        }
                     }
                 }
             }
-            for (int i = i0; i < i1; i += 2) {
-                const int r = i >> 1;
-                const bool two = i + 1 < i1;                      // the last row of an odd N has no partner (uniform)
-                const f3v nv = {k3_rowbuf[r * 9 + 0], k3_rowbuf[r * 9 + 1], k3_rowbuf[r * 9 + 2]};
-                const f3v cav = {k3_rowbuf[r * 9 + 3], k3_rowbuf[r * 9 + 4], k3_rowbuf[r * 9 + 5]};
-                const f3v cbv = {k3_rowbuf[r * 9 + 6], k3_rowbuf[r * 9 + 7], k3_rowbuf[r * 9 + 8]};
-                const uint32_t mw = rowmask[r];
-                const int so = i * row_bytes, som = i * N;
-                // plane by plane, so that only one plane's results are live at a time; each plane's results are pinned
-                // before its store (see k3_sweep)
-                auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[NC]) {
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
-                    if (live) {
-                        if (two) {
-                            put(rr, so, v);
-                        } else if constexpr (NC == 4) {
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rr, lane_off, so, POL);
-                        } else {
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rr, lane_off, so, POL);
+        }
+        staged_b = (int)b; staged_lo = r_lo; staged_hi = r_hi;
+        if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
+        __syncthreads();
+        // per plane: the staged rows as one buffer (uniform base, the lane's constant byte offset, the row's byte offset as
+        // a scalar); the flat mask stores address the whole structure
+        const size_t seg = ((size_t)b * N + (size_t)r_lo) * N, sbase = (size_t)b * N * N;
+        auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
+        const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
+                                     r_th = rs(theta + seg), r_ph = rs(phi + seg);
+        const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + (M16 ? seg : sbase)), r_mcb = rs(m_cb + (M16 ? seg : sbase)),
+                                     r_mno = rs(m_no + (M16 ? seg : sbase));
+        const int gq = lane & 15, rq = lane >> 4;                 // M16: this lane's 16-column group and row of a 4-row store
+        int c = c_lo + wave;
+        while (c < c_hi) {
+            const int chunk = c / tpc, strip0 = c - chunk * tpc;
+            const int i0 = chunk * CH - r_lo;                     // rows relative to r_lo (CH is even: pairs stay aligned)
+            const int i1 = min(i0 + CH, r_hi - r_lo);
+            // !M16: the mask bytes of 16 rows (several chunks: full lanes, and the set-up once per 16 rows), flat, plane by plane
+            // (each plane has its own 16-byte grid), by the task of their first chunk's first strip.  What a task owns must not
+            // depend on the workgroup that runs it: the rows' mask words are staged up to 16 rows beyond the workgroup's own rows.
+            if (!M16 && strip0 == 0 && (chunk * CH) % 16 == 0) {
+                const int R0 = chunk * CH, R1 = min(R0 + 16, N);
+                const unsigned rel0 = (unsigned)R0 * (unsigned)N, rel1 = (unsigned)R1 * (unsigned)N;   // bytes from the structure's first
+                const bool first = chunk == 0, more = R1 < N;     // the structure's first / not its last rows
+                auto row_word = [&](unsigned i) {                 // the three mask bits of absolute row i (staged: r_lo <= i <= r_hi)
+                    const unsigned ri = i - (unsigned)r_lo;
+                    return rowmask[ri >> 1] >> (8u * (ri & 1u));
+                };
+                // one 16-byte group of one plane: 16 bits of the column mask from column j on (zero beyond N), AND the row's
+                // bit; where the group runs into row i + 1 (N >= 100: at most once), that row's first columns
+                auto group = [&](const uint32_t* W, uint32_t bit, uint32_t w0, uint32_t w1, unsigned j, bool wrap) {
+                    const unsigned k = j >> 5, sh = j & 31u;
+                    uint32_t x = (w0 & bit) ? (__builtin_amdgcn_alignbit(W[k + 1], W[k], sh) & 0xFFFFu) : 0u;
+                    if (wrap && (w1 & bit)) x |= (W[0] << ((unsigned)N - j)) & 0xFFFFu;
+                    return k3_u32x4{((x & 15u) * 0x00204081u) & 0x01010101u, (((x >> 4) & 15u) * 0x00204081u) & 0x01010101u,
+                                    (((x >> 8) & 15u) * 0x00204081u) & 0x01010101u, (((x >> 12) & 15u) * 0x00204081u) & 0x01010101u};
+                };
+                auto span = [&](const uint8_t* first_byte, unsigned& bs, unsigned& be) {   // the whole groups that start in these rows
+                    const unsigned sb16 = (unsigned)(reinterpret_cast<uintptr_t>(first_byte) & 15u);   // the structure's first byte on the grid
+                    bs = rel0 + ((16u - ((sb16 + rel0) & 15u)) & 15u);
+                    be = more ? rel1 + ((16u - ((sb16 + rel1) & 15u)) & 15u) : rel1 - ((sb16 + rel1) & 15u);
+                };
+                auto ends = [&](const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* W, uint32_t bit, unsigned bs, unsigned be) {
+                    if ((first && bs > rel0) || (!more && be < rel1)) {   // (uniform) the structure's ends: bytes outside whole groups
+                        const bool head = lane < 16;
+                        const unsigned f = head ? rel0 + (unsigned)lane : be + (unsigned)(lane - 16);
+                        if (lane < 32 && (head ? (first && f < bs) : (!more && f < rel1))) {
+                            unsigned i = __umulhi(f, rcpN), j = f - i * (unsigned)N;
+                            if (j >= (unsigned)N) ++i, j -= (unsigned)N;
+                            const uint8_t v = (row_word(i) & bit) ? (uint8_t)((W[j >> 5] >> (j & 31u)) & 1u) : (uint8_t)0;
+                            __builtin_amdgcn_raw_buffer_store_b8(v, rsrc, (int)f, 0, POL);
                         }
                     }
                 };
-                f3v NV[NC], CAV[NC], CBV[NC], CAJ[NC], CBJ[NC];
-                f32x2 v[NC];
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) {
-                    NV[cc] = nv; CAV[cc] = cav; CBV[cc] = cbv;
-                    CAJ[cc] = mk3v(ca_j[cc], ca_j[cc]); CBJ[cc] = mk3v(cb_j[cc], cb_j[cc]);
-                }
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cav, CAJ[cc]);
-                emit(r_dca, v);
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cbv, CBJ[cc]);
-                emit(r_dcb, v);
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
-                emit(r_dno, v);
-                angle3v_n<NC>(CAV, CBV, CBJ, v);
-                emit(r_ph, v);
-                dihedral4v_k3_n<NC>(CAV, CBV, CAJ, CBJ, v);         // as coded at protstruc.py:811
-                emit(r_om, v);
-                dihedral4v_k3_n<NC>(NV, CAV, CBV, CBJ, v);
-                emit(r_th, v);
-                if (!M16 && live) {
-                    putm(r_mca, som, (mw & 2u) ? mj_ca : 0u);
-                    putm(r_mcb, som, (mw & 4u) ? mj_cb : 0u);
-                    putm(r_mno, som, (mw & 1u) ? mj_o : 0u);
-                    if (two) {
-                        putm(r_mca, som + N, (mw & 0x200u) ? mj_ca : 0u);
-                        putm(r_mcb, som + N, (mw & 0x400u) ? mj_cb : 0u);
-                        putm(r_mno, som + N, (mw & 0x100u) ? mj_o : 0u);
+                unsigned bs_ca, be_ca, bs_cb, be_cb, bs_no, be_no;
+                span(m_ca + sbase, bs_ca, be_ca); span(m_cb + sbase, bs_cb, be_cb); span(m_no + sbase, bs_no, be_no);
+                if (bs_ca == bs_cb && bs_ca == bs_no) {           // (uniform) one grid for the three planes: one decode per group
+                    for (unsigned f = bs_ca + 16u * (unsigned)lane; f < be_ca; f += 16u * 64u) {   // a store instruction writes 1 KB
+                        unsigned i = __umulhi(f, rcpN), j = f - i * (unsigned)N;
+                        if (j >= (unsigned)N) ++i, j -= (unsigned)N;
+                        const bool wrap = j + 16u > (unsigned)N;
+                        const uint32_t w0 = row_word(i), w1 = wrap ? row_word(i + 1u) : 0u;
+                        k3_u32x4 g1 = group(colbits, 2u, w0, w1, j, wrap), g2 = group(colbits + nw, 4u, w0, w1, j, wrap), g3 = group(colbits + 2 * nw, 1u, w0, w1, j, wrap);
+                        __builtin_amdgcn_raw_buffer_store_b128(g1, r_mca, (int)f, 0, POL);
+                        __builtin_amdgcn_raw_buffer_store_b128(g2, r_mcb, (int)f, 0, POL);
+                        __builtin_amdgcn_raw_buffer_store_b128(g3, r_mno, (int)f, 0, POL);
                     }
+                } else {
+                    auto plane = [&](const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t* W, uint32_t bit, unsigned bs, unsigned be) {
+                        for (unsigned f = bs + 16u * (unsigned)lane; f < be; f += 16u * 64u) {
+                            unsigned i = __umulhi(f, rcpN), j = f - i * (unsigned)N;
+                            if (j >= (unsigned)N) ++i, j -= (unsigned)N;
+                            const bool wrap = j + 16u > (unsigned)N;
+                            __builtin_amdgcn_raw_buffer_store_b128(group(W, bit, row_word(i), wrap ? row_word(i + 1u) : 0u, j, wrap), rsrc, (int)f, 0, POL);
+                        }
+                    };
+                    plane(r_mca, colbits, 2u, bs_ca, be_ca);
+                    plane(r_mcb, colbits + nw, 4u, bs_cb, be_cb);
+                    plane(r_mno, colbits + 2 * nw, 1u, bs_no, be_no);
+                }
+                ends(r_mca, colbits, 2u, bs_ca, be_ca);
+                ends(r_mcb, colbits + nw, 4u, bs_cb, be_cb);
+                ends(r_mno, colbits + 2 * nw, 1u, bs_no, be_no);
+            }
+            {
+                const int strip = strip0;
+                // this lane's NC columns of the strip
+                const int jbase = VEC ? (strip * 64 + lane) * NC : strip * 64 * NC + lane;
+                bool lv[NC];
+                f3 ca_j[NC], o_j[NC], cb_j[NC];
+                if constexpr (VEC) {                              // consecutive columns: one LDS read per coordinate
+                    const int jr = min(jbase, Np - NC);
+                    typedef typename std::conditional<NC == 4, k3_f32x4, f32x2>::type cvec;
+                    cvec t[9];
+#pragma unroll
+                    for (int qc = 0; qc < 9; ++qc) t[qc] = *reinterpret_cast<const cvec*>(colpts + qc * Np + jr);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        lv[cc] = jbase < N;                       // N % NC == 0: a lane's columns are all in or all out
+                        ca_j[cc] = f3{t[0][cc], t[1][cc], t[2][cc]};
+                        o_j[cc] = f3{t[3][cc], t[4][cc], t[5][cc]};
+                        cb_j[cc] = f3{t[6][cc], t[7][cc], t[8][cc]};
+                    }
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        const int j = jbase + 64 * cc, jr = min(j, N - 1);
+                        lv[cc] = j < N;
+                        ca_j[cc] = f3{colpts[jr], colpts[Np + jr], colpts[2 * Np + jr]};
+                        o_j[cc] = f3{colpts[3 * Np + jr], colpts[4 * Np + jr], colpts[5 * Np + jr]};
+                        cb_j[cc] = f3{colpts[6 * Np + jr], colpts[7 * Np + jr], colpts[8 * Np + jr]};
+                    }
+                }
+                const bool live = lv[0];
+                const int lane_off = jbase * 4;
+                if constexpr (M16) {                              // the strip's mask planes: four rows per store instruction
+                    const int jg = strip * 64 * NC + 16 * gq;
+                    if (jg < N) {                                 // N % 16 == 0: a group is in or out
+                        const k3_u32x4 cm_ca = *reinterpret_cast<const k3_u32x4*>(colmask + jg);
+                        const k3_u32x4 cm_cb = *reinterpret_cast<const k3_u32x4*>(colmask + N + jg);
+                        const k3_u32x4 cm_o = *reinterpret_cast<const k3_u32x4*>(colmask + 2 * N + jg);
+                        for (int k4 = i0; k4 < i1; k4 += 4) {
+                            const int rr = k4 + rq;
+                            if (rr < i1) {
+                                const uint32_t w = rowmask[rr >> 1] >> (8 * (rr & 1));
+                                const int vo = rr * N + jg;
+                                const k3_u32x4 z = {0, 0, 0, 0};
+                                __builtin_amdgcn_raw_buffer_store_b128((w & 2u) ? cm_ca : z, r_mca, vo, 0, POL);
+                                __builtin_amdgcn_raw_buffer_store_b128((w & 4u) ? cm_cb : z, r_mcb, vo, 0, POL);
+                                __builtin_amdgcn_raw_buffer_store_b128((w & 1u) ? cm_o : z, r_mno, vo, 0, POL);
+                            }
+                        }
+                    }
+                }
+                for (int i = i0; i < i1; i += 2) {
+                    const int r = i >> 1;
+                    const bool two = i + 1 < i1;                  // the last row of an odd N has no partner (uniform)
+                    const f3v nv = {k3_rowbuf[r * 9 + 0], k3_rowbuf[r * 9 + 1], k3_rowbuf[r * 9 + 2]};
+                    const f3v cav = {k3_rowbuf[r * 9 + 3], k3_rowbuf[r * 9 + 4], k3_rowbuf[r * 9 + 5]};
+                    const f3v cbv = {k3_rowbuf[r * 9 + 6], k3_rowbuf[r * 9 + 7], k3_rowbuf[r * 9 + 8]};
+                    const int so = i * row_bytes;
+                    // plane by plane, so that only one plane's results are live at a time; each plane's results are pinned
+                    // before its store (see k3_sweep)
+                    auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[NC]) {
+#pragma unroll
+                        for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
+                        if constexpr (!VEC) {
+#pragma unroll
+                            for (int cc = 0; cc < NC; ++cc)
+                                if (lv[cc]) {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].x), rr, lane_off + 256 * cc, so, POL);
+                                    if (two) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].y), rr, lane_off + 256 * cc, so + row_bytes, POL);
+                                }
+                        } else if (live) {
+                            if constexpr (NC == 4) {
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rr, lane_off, so, POL);
+                                if (two) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), rr, lane_off, so + row_bytes, POL);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rr, lane_off, so, POL);
+                                if (two) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rr, lane_off, so + row_bytes, POL);
+                            }
+                        }
+                    };
+                    f3v NV[NC], CAV[NC], CBV[NC], CAJ[NC], CBJ[NC];
+                    f32x2 v[NC];
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        NV[cc] = nv; CAV[cc] = cav; CBV[cc] = cbv;
+                        CAJ[cc] = mk3v(ca_j[cc], ca_j[cc]); CBJ[cc] = mk3v(cb_j[cc], cb_j[cc]);
+                    }
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cav, CAJ[cc]);
+                    emit(r_dca, v);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cbv, CBJ[cc]);
+                    emit(r_dcb, v);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
+                    emit(r_dno, v);
+                    angle3v_n<NC>(CAV, CBV, CBJ, v);
+                    emit(r_ph, v);
+                    dihedral4v_k3_n<NC>(CAV, CBV, CAJ, CBJ, v);     // as coded at protstruc.py:811
+                    emit(r_om, v);
+                    dihedral4v_k3_n<NC>(NV, CAV, CBV, CBJ, v);
+                    emit(r_th, v);
                 }
             }
             unsigned nx = 0;
@@ -778,41 +894,61 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
     if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || exact_angles < 0 || exact_angles > 2)
         return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    if (exact_angles == 0) {   // NC columns per lane where every store is aligned: N % NC == 0, 4 * NC-byte (masks: NC-byte) aligned planes
+    if (exact_angles == 0) {   // the per-CU sweep: any N >= K3_SWEEP_MIN_N whose rows fit in LDS
         uintptr_t alf = 0, alm = 0;
         for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
                               (const void*)theta, (const void*)phi})
             alf |= reinterpret_cast<uintptr_t>(p);
         for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
             alm |= reinterpret_cast<uintptr_t>(p);
-        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 16 + 3 * 256;   // one structure's rows: points + mask words; the strip's column mask bytes
-        const bool fits = N >= K3_SWEEP_MIN_N && need <= K3_LDS_MAX;
-        const bool ok4 = fits && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0;
-        const bool ok2 = fits && N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0;
-        if (ok4 || ok2) {
+        // one structure's rows (points + mask words), its column points, its column masks (bytes or bit sets)
+        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
+                            std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
+        if (N >= K3_SWEEP_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
+            // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
+            // columns per lane by the lanes a strip wastes
+            const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
             const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
-            const int NC = (K3_FEATURISE_NC4 && ok4 && (!ok2 || w4 <= w2)) ? 4 : 2;
+            const int NC = (K3_FEATURISE_NC4 && w4 <= w2) ? 4 : 2;
+            const bool vec = NC == 4 ? v4 : v2;
+            const bool m16 = vec && NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
+            const bool wt = m16 && N % 32 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;   // every store covers whole lines
             const int cus = k3_cu_count();
             const int n_strips = (N + 64 * NC - 1) / (64 * NC);
-            const int CH = k3_rows_per_task(N, 4);   // its 16-byte mask stores carry four rows per instruction
+            // a task is CH rows x one strip, the strips of a row chunk adjacent tasks.  Four rows (the M16 mask stores carry four
+            // rows per instruction) -- two where a structure would otherwise be fewer than eight tasks per wave (short chains;
+            // not with the M16 stores): a workgroup's share has to be many tasks per wave whatever B and N are, its waves wait
+            // for each other at every structure boundary for up to one task
+            const bool two_wg = (unsigned long long)B >= 4ull * cus;
+            const int waves = (NC == 4 ? 8 : 16) >> (two_wg ? 1 : 0);
+            const int CH = (!m16 && ((N + 3) / 4) * n_strips < 8 * waves) ? 2 : 4;
             const int n_chunks = (N + CH - 1) / CH;
-            const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
+            const unsigned long long n_tasks = (unsigned long long)n_chunks * n_strips * B;
             if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-            const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + cus - 1) / cus, 4ull);
+            // One workgroup per CU -- or, when a CU's share is four or more structures (chains of ~128 residues in large
+            // batches), TWO of half the width: staging a structure (two barriers, a round trip to L2 for its rows and column
+            // points) idles all of a workgroup's waves, and the other workgroup computes meanwhile.  Their LDS requests admit
+            // exactly one / two per CU.
+            const bool two = two_wg && need <= K3_LDS_TWO_PER_CU;
+            const int wgs = two ? 2 * cus : cus;
+            const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + wgs - 1) / wgs, 4ull);
             const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
-            const size_t dyn = std::max(need, K3_LDS_ONE_PER_CU);
+            const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
+            const unsigned rcpN = (unsigned)((1ull << 32) / (unsigned)N);
             auto go = [&](auto kernel, unsigned long long (&prepared)[1]) -> int {
                 if (const int e = k3_allow_big_lds(kernel, prepared)) return e;
                 // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves
-                return ps_launch(kernel, dim3(grid), dim3(NC == 4 ? 512 : 1024), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
+                return ps_launch(kernel, dim3(grid), dim3((NC == 4 ? 512 : 1024) >> (two ? 1 : 0)), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
                                  d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
-                                 (unsigned)n_tasks, tasks_per_wg);
+                                 (unsigned)n_tasks, tasks_per_wg, rcpN);
             };
-            static unsigned long long prep[6][1] = {{0}, {0}, {0}, {0}, {0}, {0}};
-            const bool m16 = NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // 16-byte mask stores: whole 16-column groups, aligned planes
-            if (m16) return exact_sqrt ? go(k3_featurise<true, 4, true>, prep[4]) : go(k3_featurise<false, 4, true>, prep[5]);
-            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4, false>, prep[0]) : go(k3_featurise<false, 4, false>, prep[1]);
-            return exact_sqrt ? go(k3_featurise<true, 2, false>, prep[2]) : go(k3_featurise<false, 2, false>, prep[3]);
+            static unsigned long long prep[12][1] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+            if (wt) return exact_sqrt ? go(k3_featurise<true, 4, true, true, true>, prep[0]) : go(k3_featurise<false, 4, true, true, true>, prep[1]);
+            if (m16) return exact_sqrt ? go(k3_featurise<true, 4, true, true, false>, prep[2]) : go(k3_featurise<false, 4, true, true, false>, prep[3]);
+            if (NC == 4 && vec) return exact_sqrt ? go(k3_featurise<true, 4, true, false, false>, prep[4]) : go(k3_featurise<false, 4, true, false, false>, prep[5]);
+            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4, false, false, false>, prep[6]) : go(k3_featurise<false, 4, false, false, false>, prep[7]);
+            if (vec) return exact_sqrt ? go(k3_featurise<true, 2, true, false, false>, prep[8]) : go(k3_featurise<false, 2, true, false, false>, prep[9]);
+            return exact_sqrt ? go(k3_featurise<true, 2, false, false, false>, prep[10]) : go(k3_featurise<false, 2, false, false, false>, prep[11]);
         }
     }
     const int IR = 16, thr1 = k3_one_column_threads(N);

@@ -445,18 +445,22 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
     fkeys = ["d_ca", "d_cb", "d_no", "omega", "theta", "phi"]
     mkeys = ["d_ca_mask", "d_cb_mask", "d_no_mask"]
     with _on(dev):
-        f = torch.empty(6, B, N, N, dtype=torch.float32, device=dev)
-        k = torch.empty(3, B, N, N, dtype=torch.bool, device=dev)
+        # nine planes in two allocations, every plane on a 16-byte boundary (plane stride padded): the kernel's flat mask
+        # stores then share one 16-byte grid and decode each group once for the three mask planes (any N)
+        plane = B * N * N
+        fstride, kstride = (plane + 3) & ~3, (plane + 15) & ~15
+        f = torch.empty(6, fstride, dtype=torch.float32, device=dev)
+        k = torch.empty(3, kstride, dtype=torch.bool, device=dev)
         rc = 0
         if not (B == 0 or N == 0):   # empty input: nothing to launch (an empty tensor has no device pointer)
-            fp, kp, plane = f.data_ptr(), k.data_ptr(), B * N * N     # plane addresses by arithmetic, not by 9 views
-            rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * plane * i for i in range(6)],
-                                                           *[kp + plane * i for i in range(3)], B, N, A,
+            fp, kp = f.data_ptr(), k.data_ptr()                       # plane addresses by arithmetic, not by 9 views
+            rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * fstride * i for i in range(6)],
+                                                           *[kp + kstride * i for i in range(3)], B, N, A,
                                                            _lib.get_tuning("k1_exact_sqrt", dev),
                                                            _lib.get_exact_angles(dev), _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
-    out = dict(zip(fkeys, f.unbind(0)))
-    out.update(zip(mkeys, k.unbind(0)))
+    out = {key: f[i, :plane].view(B, N, N) for i, key in enumerate(fkeys)}
+    out.update({key: k[i, :plane].view(B, N, N) for i, key in enumerate(mkeys)})
     return out
 
 

@@ -1687,10 +1687,11 @@ def test_inter_residue_geometry_golden(SB):
             assert_close(v, g[k], bad_frac=1.0 / g[k].numel())
 
 
-# 100, 258, 34: two columns per lane (one / three strips, a partly idle wave); 101: odd, the one-column kernel; 256, 512: four
-# columns per lane with 16-byte mask stores; 208: the same with a partial last strip (13 of 16 column groups live); 200: four
-# columns per lane, N % 16 != 0 -> dword mask stores
-@pytest.mark.parametrize("N", [100, 101, 258, 34, 256, 200, 208, 512])
+# 34: below the per-CU sweep (one-column kernel); 256, 512: four columns per lane, vector stores, strip-local 16-byte mask
+# stores; 208: the same with a partial last strip (13 of 16 column groups live); 200, 500: four columns, vector float stores,
+# flat mask stores; 258, 100: two columns per lane (vector); 101, 129: odd, two columns, 64-floats-per-store layout; 301: the
+# same with three strips; 511, 257: odd, four columns
+@pytest.mark.parametrize("N", [100, 101, 258, 34, 256, 200, 208, 512, 129, 301, 257, 511, 500])
 def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     """The fused featuriser must equal the K1 slices -- in BOTH square-root modes of the device (it takes the mode K1
     takes: the hardware square root by default, the correctly rounded one after set_exact_sqrt(True)), the two modes
@@ -1723,6 +1724,52 @@ def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     assert same(geo["phi"], sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
     fm = SB.from_xyz(xyz, mask.float()).inter_residue_geometry()
     assert fm["d_ca_mask"].dtype == torch.float32 and torch.equal(fm["d_ca_mask"].bool(), geo["d_ca_mask"])
+
+
+@pytest.mark.parametrize("N,B", [(101, 3), (200, 2), (258, 2), (511, 2), (129, 5), (256, 2), (1030, 1)])
+def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
+    """The featuriser's per-CU sweep through the C ABI with planes the caller placed anywhere: float planes on 4-byte and
+    mask planes on 1-byte boundaries (each plane its own), sentinels in front of, between and behind the planes.  Every
+    plane must equal the one-column kernel's (exact_angles = 2: same arithmetic, the plain layout) bit for bit and no
+    sentinel may change -- the flat 16-byte mask stores, their byte-store fringes and the 64-floats-per-store layout all
+    have to land exactly on their plane."""
+    from protstruc_amd import _lib
+    from protstruc_amd.ops import _ptr, _stream
+    xyz, mask = synth(500 + N, B, N)
+    mask[0, N // 2] = False
+    mask[B - 1, :, 4] = False            # a structure without CB
+    xg, mg = xyz.cuda(), mask.cuda().to(torch.uint8)
+    plane, pad = B * N * N, 40
+    lib = _lib.load()
+
+    def run(mode, f_shift, m_shift):
+        fbuf = torch.full((6 * (plane + pad) + pad,), 777.0, device="cuda")
+        mbuf = torch.full((3 * (plane + pad) + pad,), 7, dtype=torch.uint8, device="cuda")
+        foff = [pad + i * (plane + pad) + f_shift[i] for i in range(6)]
+        moff = [pad + i * (plane + pad) + m_shift[i] for i in range(3)]
+        rc = lib.ps_inter_residue_geometry_f32(_ptr(xg), _ptr(mg), *[fbuf.data_ptr() + 4 * o for o in foff],
+                                               *[mbuf.data_ptr() + o for o in moff], B, N, 15, 0, mode, _stream(xg))
+        assert rc == 0
+        torch.cuda.synchronize()
+        fs = [fbuf[o:o + plane] for o in foff]
+        ms = [mbuf[o:o + plane] for o in moff]
+        keepf = torch.ones_like(fbuf, dtype=torch.bool)
+        keepm = torch.ones_like(mbuf, dtype=torch.bool)
+        for o in foff:
+            keepf[o:o + plane] = False
+        for o in moff:
+            keepm[o:o + plane] = False
+        assert (fbuf[keepf] == 777.0).all() and (mbuf[keepm] == 7).all(), (N, B, mode, f_shift, m_shift)
+        return fs, ms
+
+    ref_f, ref_m = run(2, [0] * 6, [0] * 3)
+    for f_shift, m_shift in (([0] * 6, [0] * 3), ([1, 2, 3, 0, 1, 2], [1, 5, 3]), ([0] * 6, [15, 8, 4])):
+        fs, ms = run(0, f_shift, m_shift)
+        for k in range(6):
+            assert torch.equal(fs[k].isnan(), ref_f[k].isnan()) and torch.equal(fs[k].nan_to_num(0), ref_f[k].nan_to_num(0)), (N, k, f_shift)
+        for k in range(3):
+            assert torch.equal(ms[k], ref_m[k]), (N, k, m_shift)
+            assert int(ms[k].max()) <= 1
 
 
 def test_fused_diffuse_frames(SB):
