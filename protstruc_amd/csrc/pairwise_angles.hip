@@ -247,14 +247,18 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
             for (int k = 0; k < NP; ++k) pj[c][k] = ((SRC >> k) & 1) ? load3(sj + sel.atom[k] * 3) : mk3(0.f, 0.f, 0.f);
         }
         if (NPI > 0 && (b != staged_b || r_lo != staged_lo || r_hi != staged_hi)) {
+            // a row per thread, its 3 * NPI loads in flight together (an element per thread walked three dependent round
+            // trips to L2 per 512-row segment)
             float* rb = reinterpret_cast<float*>(k3_rowbuf);
-            const int n_el = (r_hi - r_lo) * NPI * 3;
-            for (int e = (int)threadIdx.x; e < n_el; e += (int)blockDim.x) {
-                const int row = e / (NPI * 3), rem = e - row * (NPI * 3), q = rem / 3, c = rem - q * 3;
-                int at = amap[0];
+            for (int row = (int)threadIdx.x; row < r_hi - r_lo; row += (int)blockDim.x) {
+                const float* pr = xb + (size_t)(r_lo + row) * (size_t)A * 3;
+                float v[NPIq * 3];
 #pragma unroll
-                for (int t = 1; t < NPI; ++t) at = (q == t) ? amap[t] : at;
-                rb[((((row >> 1) * NPI + q) * 3 + c) << 1) + (row & 1)] = xb[(size_t)(r_lo + row) * (size_t)A * 3 + at * 3 + c];
+                for (int q = 0; q < NPI; ++q) {
+                    v[q * 3] = pr[amap[q] * 3]; v[q * 3 + 1] = pr[amap[q] * 3 + 1]; v[q * 3 + 2] = pr[amap[q] * 3 + 2];
+                }
+#pragma unroll
+                for (int qc = 0; qc < NPI * 3; ++qc) rb[(((row >> 1) * (NPI * 3) + qc) << 1) + (row & 1)] = v[qc];
             }
             staged_b = b; staged_lo = r_lo; staged_hi = r_hi;
         }
