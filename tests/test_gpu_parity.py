@@ -1726,18 +1726,13 @@ def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     assert fm["d_ca_mask"].dtype == torch.float32 and torch.equal(fm["d_ca_mask"].bool(), geo["d_ca_mask"])
 
 
-@pytest.mark.parametrize("N,B", [(101, 3), (200, 2), (258, 2), (511, 2), (129, 5), (256, 2), (1030, 1)])
-def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
-    """The featuriser's per-CU sweep through the C ABI with planes the caller placed anywhere: float planes on 4-byte and
-    mask planes on 1-byte boundaries (each plane its own), sentinels in front of, between and behind the planes.  Every
-    plane must equal the one-column kernel's (exact_angles = 2: same arithmetic, the plain layout) bit for bit and no
-    sentinel may change -- the flat 16-byte mask stores, their byte-store fringes and the 64-floats-per-store layout all
-    have to land exactly on their plane."""
+def _featuriser_in_sentinels(xyz, mask, shifts, exact_sqrt=0):
+    """ps_inter_residue_geometry_f32 into planes placed `shifts` = [(6 float shifts in floats, 3 mask shifts in bytes), ...]
+    away from their slots inside sentinel-filled buffers, each compared bit for bit with the one-column kernel
+    (exact_angles = 2: same arithmetic, the plain layout); no sentinel may change."""
     from protstruc_amd import _lib
     from protstruc_amd.ops import _ptr, _stream
-    xyz, mask = synth(500 + N, B, N)
-    mask[0, N // 2] = False
-    mask[B - 1, :, 4] = False            # a structure without CB
+    B, N = xyz.shape[:2]
     xg, mg = xyz.cuda(), mask.cuda().to(torch.uint8)
     plane, pad = B * N * N, 40
     lib = _lib.load()
@@ -1748,7 +1743,7 @@ def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
         foff = [pad + i * (plane + pad) + f_shift[i] for i in range(6)]
         moff = [pad + i * (plane + pad) + m_shift[i] for i in range(3)]
         rc = lib.ps_inter_residue_geometry_f32(_ptr(xg), _ptr(mg), *[fbuf.data_ptr() + 4 * o for o in foff],
-                                               *[mbuf.data_ptr() + o for o in moff], B, N, 15, 0, mode, _stream(xg))
+                                               *[mbuf.data_ptr() + o for o in moff], B, N, 15, exact_sqrt, mode, _stream(xg))
         assert rc == 0
         torch.cuda.synchronize()
         fs = [fbuf[o:o + plane] for o in foff]
@@ -1763,13 +1758,50 @@ def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
         return fs, ms
 
     ref_f, ref_m = run(2, [0] * 6, [0] * 3)
-    for f_shift, m_shift in (([0] * 6, [0] * 3), ([1, 2, 3, 0, 1, 2], [1, 5, 3]), ([0] * 6, [15, 8, 4])):
+    for f_shift, m_shift in shifts:
         fs, ms = run(0, f_shift, m_shift)
         for k in range(6):
-            assert torch.equal(fs[k].isnan(), ref_f[k].isnan()) and torch.equal(fs[k].nan_to_num(0), ref_f[k].nan_to_num(0)), (N, k, f_shift)
+            assert torch.equal(fs[k].isnan(), ref_f[k].isnan()) and torch.equal(fs[k].nan_to_num(0), ref_f[k].nan_to_num(0)), (N, B, k, f_shift)
         for k in range(3):
-            assert torch.equal(ms[k], ref_m[k]), (N, k, m_shift)
+            assert torch.equal(ms[k], ref_m[k]), (N, B, k, m_shift)
             assert int(ms[k].max()) <= 1
+
+
+def test_inter_residue_geometry_differential_fuzz(SB):
+    """Random lengths (100 .. 700: one to three strips, every residue of the length modulo 16), batch sizes, masks and plane
+    placements: the per-CU featuriser (vector / 64-floats-per-store float planes, strip-local / flat mask stores, one or
+    two workgroups per CU) against the one-column kernel, bit for bit, inside sentinels."""
+    rng = torch.Generator().manual_seed(20241004)
+    for trial in range(36):
+        N = int(torch.randint(100, 701, (1,), generator=rng))
+        if trial % 6 == 0:
+            N = (N // 16) * 16                   # the strip-local mask form
+        B = int(torch.randint(1, 5, (1,), generator=rng)) if N > 200 else int(torch.randint(1, 40, (1,), generator=rng))
+        xyz, mask = synth(7000 + trial, B, N)
+        keep = float(torch.rand(1, generator=rng))
+        mask = torch.rand(B, N, 15, generator=rng) < keep
+        if trial % 5 == 0:
+            mask = None if trial % 10 == 0 else torch.ones(B, N, 15, dtype=torch.bool)
+        fsh = [int(v) for v in torch.randint(0, 4, (6,), generator=rng)] if trial % 2 else [0] * 6
+        msh = [int(v) for v in torch.randint(0, 16, (3,), generator=rng)] if trial % 3 else [0] * 3
+        if mask is None:
+            mask_t = torch.ones(B, N, 15, dtype=torch.bool)
+        else:
+            mask_t = mask
+        _featuriser_in_sentinels(xyz, mask_t, [(fsh, msh)], exact_sqrt=trial % 2)
+
+
+@pytest.mark.parametrize("N,B", [(101, 3), (200, 2), (258, 2), (511, 2), (129, 5), (256, 2), (1030, 1)])
+def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
+    """The featuriser's per-CU sweep through the C ABI with planes the caller placed anywhere: float planes on 4-byte and
+    mask planes on 1-byte boundaries (each plane its own), sentinels in front of, between and behind the planes.  Every
+    plane must equal the one-column kernel's (exact_angles = 2: same arithmetic, the plain layout) bit for bit and no
+    sentinel may change -- the flat 16-byte mask stores, their byte-store fringes and the 64-floats-per-store layout all
+    have to land exactly on their plane."""
+    xyz, mask = synth(500 + N, B, N)
+    mask[0, N // 2] = False
+    mask[B - 1, :, 4] = False            # a structure without CB
+    _featuriser_in_sentinels(xyz, mask, [([0] * 6, [0] * 3), ([1, 2, 3, 0, 1, 2], [1, 5, 3]), ([0] * 6, [15, 8, 4])])
 
 
 def test_fused_diffuse_frames(SB):
