@@ -456,8 +456,8 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
 //     the row's bit, the next row's where the group wraps, spread to bytes: a store instruction writes 1 KB.  The task of every
 //     fourth chunk's first strip writes the masks of 16 rows (full lanes, one set-up).  Only at a structure's two ends are
 //     the bytes outside whole groups written as bytes.
-//   * WT: write-through stores (sc1) where every store covers whole 128-byte lines (N % 32 == 0); write-back otherwise,
-//     so that lines shared by two stores merge in L2 instead of going out as two partial writes.
+//   * WT: write-through stores (sc1) where every store covers whole 128-byte lines and strips are whole (N % 128 == 0);
+//     write-back otherwise, so that lines shared by two stores merge in L2 instead of going out as two partial writes.
 template <bool EXACT, int NC, bool VEC, bool M16, bool WT>
 __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
@@ -485,10 +485,9 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     const int row_bytes = N * 4;
     int staged_b = -1, staged_lo = -1, staged_hi = -1;
     // tasks of one structure: (chunk of CH rows, strip), a chunk's strips adjacent.  (Tried: a chunk of two rows x ALL strips,
-    // the wave walking the strips inside the row pair, so that every 64-byte segment two stores share -- a row's strips, a
-    // row's end and the next row's start -- is completed by one wave within a trip: 2.2 % of the write requests at N = 500 are
-    // 32-byte partials, none at N = 496 whose rows are whole segments, profiles/r04_featuriser_pmc.log.  It was 3-7 %
-    // SLOWER, N = 500 267 against 259 us: the column points then come from LDS every trip.)
+    // the wave walking the strips inside the row pair, so that every 64-byte segment two stores share is completed by one
+    // wave within a trip: 3-7 % SLOWER than four-row tasks per strip, N = 500 267 against 259 us -- the column points then
+    // come from LDS every trip.  Two-row tasks per strip are what helped: see the launcher.)
     const int tpc = n_strips;                                         // tasks per chunk
     const unsigned n_sub = (unsigned)n_chunks * (unsigned)tpc;
     for (unsigned b = t0 / n_sub; b <= (t1 - 1u) / n_sub; ++b) {       // the structures of this workgroup's tasks
@@ -916,16 +915,21 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             const int NC = (K3_FEATURISE_NC4 && w4 <= w2) ? 4 : 2;
             const bool vec = NC == 4 ? v4 : v2;
             const bool m16 = vec && NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
-            const bool wt = m16 && N % 32 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;   // every store covers whole lines
+            // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
+            // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
+            const bool wt = m16 && N % 128 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;
             const int cus = k3_cu_count();
             const int n_strips = (N + 64 * NC - 1) / (64 * NC);
-            // a task is CH rows x one strip, the strips of a row chunk adjacent tasks.  Four rows (the M16 mask stores carry four
-            // rows per instruction) -- two where a structure would otherwise be fewer than eight tasks per wave (short chains;
-            // not with the M16 stores): a workgroup's share has to be many tasks per wave whatever B and N are, its waves wait
-            // for each other at every structure boundary for up to one task
+            // a task is CH rows x one strip, the strips of a row chunk adjacent tasks: a workgroup's share has to be many tasks
+            // per wave whatever B and N are -- its waves wait for each other at every structure boundary for up to one task.
+            // Four rows with the M16 mask stores (four rows per instruction; rows are whole 64-byte segments there).  TWO
+            // otherwise: where rows are not whole segments, the segment a row's strips share and the one a row's end shares with
+            // the next row's start get their halves from adjacent tasks, i.e. from two waves up to a task apart -- with
+            // four-row tasks (~16 us) longer than a line stays in L2 at this store rate, so that half of them went out as two
+            // partial writes (2.2 % of the write requests at N = 500, none at N = 496: profiles/r04_featuriser_pmc.log);
+            // same-box A/B, trace: N = 500 260 -> 228 us, 511 264 -> 241, 255 238 -> 218.
             const bool two_wg = (unsigned long long)B >= 4ull * cus;
-            const int waves = (NC == 4 ? 8 : 16) >> (two_wg ? 1 : 0);
-            const int CH = (!m16 && ((N + 3) / 4) * n_strips < 8 * waves) ? 2 : 4;
+            const int CH = m16 ? 4 : 2;
             const int n_chunks = (N + CH - 1) / CH;
             const unsigned long long n_tasks = (unsigned long long)n_chunks * n_strips * B;
             if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;

@@ -1,7 +1,7 @@
 #!/usr/bin/python3
 """K3 across chain lengths at a fixed number of residue pairs (2^25): the dispatcher's pick (per-CU sweep kernels for even N)
 against the one-column kernel (reached through a 4-byte-misaligned output), HIP events over a train of launches.
-   python3 tools/k3_shapes.py [reps]"""
+   python3 tools/k3_shapes.py [reps] [N ...]"""
 import os
 import sys
 
@@ -27,7 +27,7 @@ def timed(fn):
 
 
 print("us per launch, 2^25 residue pairs (134 MB) per launch;  dihedral (2,2) / dihedral (3,1) / planar (2,1)")
-for N in (512, 384, 256, 200, 128, 100, 64, 48, 32, 16, 511, 255):
+for N in ([int(v) for v in sys.argv[2:]] or [512, 384, 256, 200, 128, 100, 64, 48, 32, 16, 511, 255]):
     B = max(1, (1 << 25) // (N * N))
     g = torch.Generator().manual_seed(N)
     xyz = torch.randn(B, N, 15, 3, generator=g).cuda()
