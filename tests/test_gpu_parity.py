@@ -1791,7 +1791,8 @@ def test_inter_residue_geometry_differential_fuzz(SB):
         _featuriser_in_sentinels(xyz, mask_t, [(fsh, msh)], exact_sqrt=trial % 2)
 
 
-@pytest.mark.parametrize("N,B", [(101, 3), (200, 2), (258, 2), (511, 2), (129, 5), (256, 2), (1030, 1)])
+# ... 2048: the longest chain whose rows, column points and masks fit in LDS (158 KB); 2100: beyond it (one-column kernel)
+@pytest.mark.parametrize("N,B", [(101, 3), (200, 2), (258, 2), (511, 2), (129, 5), (256, 2), (1030, 1), (2048, 1), (2100, 1)])
 def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
     """The featuriser's per-CU sweep through the C ABI with planes the caller placed anywhere: float planes on 4-byte and
     mask planes on 1-byte boundaries (each plane its own), sentinels in front of, between and behind the planes.  Every
