@@ -1402,23 +1402,32 @@ def test_k3_inside_a_captured_graph(SB):
     tools/microbench/capture_attr_test.hip, profiles/r04_capture_attr_test.log).  Captured launches of K3 must replay to
     the eager result bit for bit."""
     from protstruc_amd import ops
-    xyz, mask = synth(4242, 2, 64)
-    xg = xyz.cuda()
+    N = 134                                      # a per-CU sweep length (>= 100) that no other test launches these splits at
+    xyz, mask = synth(4242, 2, N)
+    xg, mg = xyz.cuda(), mask.cuda()
     si, sj = [3, 0], [2, 1]                      # O_i, N_i | C_j, CA_j
     si2, sj2 = [3], [0, 2, 1]                    # planar O_i | N_j, C_j
-    out = torch.empty(2, 64, 64, device="cuda")
-    out2 = torch.empty(2, 64, 64, device="cuda")
+    out = torch.empty(2, N, N, device="cuda")
+    out2 = torch.empty(2, N, N, device="cuda")
+    xo, mo = synth(4243, 3, 131)                 # odd: the featuriser's 64-floats-per-store layout with flat mask stores
+    xog, mog = xo.cuda(), mo.cuda()
     side = torch.cuda.Stream()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(g, stream=side):
             ops.pairwise_angles(xg, si, sj, 4, out=out)
             ops.pairwise_angles(xg, si2, sj2, 3, out=out2)
+            geo = ops.inter_residue_geometry(xog, mog)
     out.fill_(7.0); out2.fill_(7.0)
+    for v in geo.values():
+        v.fill_(1)
     g.replay()
     torch.cuda.synchronize()
     same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
     assert same(out, ops.pairwise_angles(xg, si, sj, 4)) and same(out2, ops.pairwise_angles(xg, si2, sj2, 3))
+    eager = ops.inter_residue_geometry(xog, mog)
+    for k, v in geo.items():
+        assert (torch.equal(v, eager[k]) if v.dtype == torch.bool else same(v, eager[k])), k
 
 
 def test_k3_errors(SB):
