@@ -200,6 +200,72 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
 // VEC = false (odd N, or an output that is not 4 * NC-byte aligned): the lane's NC columns are 64 apart instead of adjacent
 // (column = strip * 64 * NC + 64 * c + lane), so every store instruction writes 64 consecutive floats of one row -- no
 // alignment is needed at all -- at the price of NC dword stores per row instead of one vector store.
+// One task's row pairs for L of the lane's NC columns (see the kernel; pinned results and interleaved chains as described there).
+#define K3_SWEEP_ROWS(L)                                                                                                  \
+    {                                                                                                                     \
+            int i = i0;                                                                                                  \
+            for (; i + 1 < i1; i += 2) {                                                                                 \
+                f3v cur[NP];                                                                                             \
+                rows(i >> 1, cur);                                                                                       \
+                f3v P[NP][L];                                                                                            \
+_Pragma("unroll")                                                                                                        \
+                for (int k = 0; k < NP; ++k)                                                                             \
+_Pragma("unroll")                                                                                                        \
+                    for (int cc = 0; cc < L; ++cc) P[k][cc] = ((SRC >> k) & 1) ? mk3v(pj[cc][k], pj[cc][k]) : cur[k];    \
+                f32x2 v[L];                                                                                              \
+                if constexpr (NP == 4)                                                                                   \
+                    dihedral4v_k3_n<L>(P[0], P[1], P[2], P[3], v);                                                       \
+                else                                                                                                     \
+                    angle3v_n<L>(P[0], P[1], P[2], v);                                                                   \
+_Pragma("unroll")                                                                                                        \
+                for (int cc = 0; cc < L; ++cc) asm volatile("" : "+v"(v[cc]));                                           \
+                if constexpr (!VEC) {                                                                                    \
+                    const int so = i * row_bytes;                                                                        \
+_Pragma("unroll")                                                                                                        \
+                    for (int cc = 0; cc < L; ++cc)                                                                       \
+                        if (j0 + 64 * cc < N) {                                                                          \
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].x), rsrc, lane_off + 256 * cc, so, POL); \
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].y), rsrc, lane_off + 256 * cc, so + row_bytes, POL); \
+                        }                                                                                                \
+                } else if (live) {                                                                                       \
+                    const int so = i * row_bytes;                                                                        \
+                    if constexpr (NC == 4) {                                                                             \
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rsrc, lane_off, so, POL); \
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), rsrc, lane_off, so + row_bytes, POL); \
+                    } else {                                                                                             \
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lane_off, so, POL); \
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, lane_off, so + row_bytes, POL); \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }                                                                                                            \
+            if (i < i1) {                                                                                                \
+                f3v cur[NP];                                                                                             \
+                rows(i >> 1, cur);                                                                                       \
+                float v[NC];                                                                                             \
+_Pragma("unroll")                                                                                                        \
+                for (int cc = 0; cc < L; ++cc) {                                                                         \
+                    f3 p[NP];                                                                                            \
+_Pragma("unroll")                                                                                                        \
+                    for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[cc][k] : mk3(cur[k].x.x, cur[k].y.x, cur[k].z.x); \
+                    if constexpr (NP == 4)                                                                               \
+                        v[cc] = dihedral4_k3(p[0], p[1], p[2], p[3]);                                                    \
+                    else                                                                                                 \
+                        v[cc] = angle3(p[0], p[1], p[2]);                                                                \
+                }                                                                                                        \
+                if constexpr (!VEC) {                                                                                    \
+                    const int so = i * row_bytes;                                                                        \
+_Pragma("unroll")                                                                                                        \
+                    for (int cc = 0; cc < L; ++cc)                                                                       \
+                        if (j0 + 64 * cc < N) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc]), rsrc, lane_off + 256 * cc, so, POL); \
+                } else if (live) {                                                                                       \
+                    const int so = i * row_bytes;                                                                        \
+                    if constexpr (NC == 4)                                                                               \
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0], v[1], v[2], v[3]}), rsrc, lane_off, so, POL); \
+                    else                                                                                                 \
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0], v[1]}), rsrc, lane_off, so, POL); \
+                }                                                                                                        \
+            }                                                                                                            \
+    }
 template <int NP, int SRC, int NC, bool VEC>
 __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                  AtomSel sel, int row_begin, int row_end, int out_rows,
@@ -284,69 +350,19 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
         while (c < c_hi) {
             const int i0 = (c - c_lo) * CH;                       // rows relative to r_lo (CH is even: pairs stay aligned)
             const int i1 = min(i0 + CH, r_hi - r_lo);
-            int i = i0;
-            for (; i + 1 < i1; i += 2) {
-                f3v cur[NP];
-                rows(i >> 1, cur);
-                f3v P[NP][NC];
-#pragma unroll
-                for (int k = 0; k < NP; ++k)
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) P[k][cc] = ((SRC >> k) & 1) ? mk3v(pj[cc][k], pj[cc][k]) : cur[k];
-                f32x2 v[NC];
-                if constexpr (NP == 4)
-                    dihedral4v_k3_n<NC>(P[0], P[1], P[2], P[3], v);
-                else
-                    angle3v_n<NC>(P[0], P[1], P[2], v);
-                // the results are pinned HERE: otherwise the compiler sinks the arithmetic into the `live` branch below, away
-                // from the scheduling barriers that interleave the columns' chains, and the chains serialise again
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
-                if constexpr (!VEC) {
-                    const int so = i * row_bytes;
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc)
-                        if (j0 + 64 * cc < N) {
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].x), rsrc, lane_off + 256 * cc, so, POL);
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].y), rsrc, lane_off + 256 * cc, so + row_bytes, POL);
-                        }
-                } else if (live) {
-                    const int so = i * row_bytes;
-                    if constexpr (NC == 4) {
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].x, v[1].x, v[2].x, v[3].x}), rsrc, lane_off, so, POL);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0].y, v[1].y, v[2].y, v[3].y}), rsrc, lane_off, so + row_bytes, POL);
-                    } else {
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lane_off, so, POL);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, lane_off, so + row_bytes, POL);
-                    }
-                }
-            }
-            if (i < i1) {   // odd last row of the row range
-                f3v cur[NP];
-                rows(i >> 1, cur);
-                float v[NC];
-#pragma unroll
-                for (int cc = 0; cc < NC; ++cc) {
-                    f3 p[NP];
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[cc][k] : mk3(cur[k].x.x, cur[k].y.x, cur[k].z.x);
-                    if constexpr (NP == 4)
-                        v[cc] = dihedral4_k3(p[0], p[1], p[2], p[3]);
-                    else
-                        v[cc] = angle3(p[0], p[1], p[2]);
-                }
-                if constexpr (!VEC) {
-                    const int so = i * row_bytes;
-#pragma unroll
-                    for (int cc = 0; cc < NC; ++cc)
-                        if (j0 + 64 * cc < N) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc]), rsrc, lane_off + 256 * cc, so, POL);
-                } else if (live) {
-                    const int so = i * row_bytes;
-                    if constexpr (NC == 4)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{v[0], v[1], v[2], v[3]}), rsrc, lane_off, so, POL);
-                    else
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0], v[1]}), rsrc, lane_off, so, POL);
-                }
+            // the row pairs of the task (K3_SWEEP_ROWS, defined in front of the kernel; a macro rather than a generic lambda: inside
+            // a lambda the register allocator spilled 1-30 registers in four instantiations).  !VEC: a strip may have fewer than NC
+            // live column groups (64 columns each; the last strip of a row) -- the chains of the dead ones are not evaluated.
+            if constexpr (VEC) {
+                K3_SWEEP_ROWS(NC)
+            } else {
+                // (not three of four, and nothing for the (2,2) dihedral at four columns: with those variants that instantiation
+                // spilled 3-5 registers)
+                constexpr bool SKIP = !(NP == 4 && SRC == 12 && NC == 4);
+                const int ncl = SKIP ? min(NC, (N - strip * 64 * NC + 63) >> 6) : NC;   // live column groups of this strip (uniform)
+                if (!SKIP || ncl == NC || ncl == 3) K3_SWEEP_ROWS(NC)
+                else if (NC == 4 && ncl == 2) K3_SWEEP_ROWS((NC == 4 ? 2 : 1))
+                else K3_SWEEP_ROWS(1)
             }
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
@@ -354,6 +370,8 @@ __global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, 
         }
     }
 }
+
+#undef K3_SWEEP_ROWS
 
 // Fused trRosetta featuriser (reference protstruc.py:790-817): the three atom-pair planes of K1 that
 // inter_residue_geometry slices out (CA-CA, CB-CB, N-O), their masks, and the three K3 features, in
@@ -693,6 +711,10 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                         }
                     }
                 }
+                // !VEC: the last strip of a row may have fewer than NC live column groups (64 columns each) -- the chains of
+                // the dead ones are not evaluated (N = 129 at NC = 4: three of four; N = 300 at NC = 2: one of two)
+                auto sweep_rows = [&](auto ncl_tag) {
+                constexpr int L = decltype(ncl_tag)::value;
                 for (int i = i0; i < i1; i += 2) {
                     const int r = i >> 1;
                     const bool two = i + 1 < i1;                  // the last row of an odd N has no partner (uniform)
@@ -702,12 +724,12 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                     const int so = i * row_bytes;
                     // plane by plane, so that only one plane's results are live at a time; each plane's results are pinned
                     // before its store (see k3_sweep)
-                    auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[NC]) {
+                    auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[L]) {
 #pragma unroll
-                        for (int cc = 0; cc < NC; ++cc) asm volatile("" : "+v"(v[cc]));
+                        for (int cc = 0; cc < L; ++cc) asm volatile("" : "+v"(v[cc]));
                         if constexpr (!VEC) {
 #pragma unroll
-                            for (int cc = 0; cc < NC; ++cc)
+                            for (int cc = 0; cc < L; ++cc)
                                 if (lv[cc]) {
                                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].x), rr, lane_off + 256 * cc, so, POL);
                                     if (two) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[cc].y), rr, lane_off + 256 * cc, so + row_bytes, POL);
@@ -722,28 +744,38 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                             }
                         }
                     };
-                    f3v NV[NC], CAV[NC], CBV[NC], CAJ[NC], CBJ[NC];
-                    f32x2 v[NC];
+                    f3v NV[L], CAV[L], CBV[L], CAJ[L], CBJ[L];
+                    f32x2 v[L];
 #pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) {
+                    for (int cc = 0; cc < L; ++cc) {
                         NV[cc] = nv; CAV[cc] = cav; CBV[cc] = cbv;
                         CAJ[cc] = mk3v(ca_j[cc], ca_j[cc]); CBJ[cc] = mk3v(cb_j[cc], cb_j[cc]);
                     }
 #pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cav, CAJ[cc]);
+                    for (int cc = 0; cc < L; ++cc) v[cc] = dist3v_t<EXACT>(cav, CAJ[cc]);
                     emit(r_dca, v);
 #pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(cbv, CBJ[cc]);
+                    for (int cc = 0; cc < L; ++cc) v[cc] = dist3v_t<EXACT>(cbv, CBJ[cc]);
                     emit(r_dcb, v);
 #pragma unroll
-                    for (int cc = 0; cc < NC; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
+                    for (int cc = 0; cc < L; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
                     emit(r_dno, v);
-                    angle3v_n<NC>(CAV, CBV, CBJ, v);
+                    angle3v_n<L>(CAV, CBV, CBJ, v);
                     emit(r_ph, v);
-                    dihedral4v_k3_n<NC>(CAV, CBV, CAJ, CBJ, v);     // as coded at protstruc.py:811
+                    dihedral4v_k3_n<L>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
                     emit(r_om, v);
-                    dihedral4v_k3_n<NC>(NV, CAV, CBV, CBJ, v);
+                    dihedral4v_k3_n<L>(NV, CAV, CBV, CBJ, v);
                     emit(r_th, v);
+                }
+                };
+                if constexpr (VEC) {
+                    sweep_rows(std::integral_constant<int, NC>{});
+                } else {
+                    const int ncl = min(NC, (N - strip * 64 * NC + 63) >> 6);   // live column groups of this strip (uniform)
+                    if (ncl == NC) sweep_rows(std::integral_constant<int, NC>{});
+                    else if (NC == 4 && ncl == 3) sweep_rows(std::integral_constant<int, NC == 4 ? 3 : 1>{});
+                    else if (NC == 4 && ncl == 2) sweep_rows(std::integral_constant<int, NC == 4 ? 2 : 1>{});
+                    else sweep_rows(std::integral_constant<int, 1>{});
                 }
             }
             unsigned nx = 0;
@@ -830,16 +862,21 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const bool ok4 = NC4 && fits && N % 4 == 0 && (al & 15u) == 0, ok2 = fits && N % 2 == 0 && (al & 7u) == 0;
     // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
     const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
-    if (ok4 || ok2) {
+    // The 64-apart layout skips the dead column groups of a row's last strip: it computes ceil(N / 64) groups per row pair
+    // where the vector layouts compute whole strips -- taken also for even N where that saves more than its dword stores cost
+    const long long gn = (N + 63) / 64, gv = (NC4 && ok4 && (!ok2 || w4 <= w2) ? w4 : w2) / 64;
+    constexpr bool SKIPS = !(NP == 4 && SRC == 12);   // (the (2,2) dihedral's four-column instantiation evaluates every group: registers)
+    if ((ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100)) {
         if constexpr (NC4) {
             if (ok4 && (!ok2 || w4 <= w2))
                 return launch_sweep<NP, SRC, 4, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
         }
         return launch_sweep<NP, SRC, 2, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
     }
-    if (fits) {   // odd N or a misaligned output: the same sweep with the lane's columns 64 apart and dword stores
-        if constexpr (NC4) {
-            if (w4 <= w2) return launch_sweep<NP, SRC, 4, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+    if (fits) {   // odd N, a misaligned output, or fewer groups: the same sweep with the lane's columns 64 apart and dword stores
+        if constexpr (NC4) {   // four columns from three groups on where dead groups are skipped; else by the lanes a strip wastes
+            if (SKIPS ? gn > 2 : w4 <= w2)
+                return launch_sweep<NP, SRC, 4, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
         }
         return launch_sweep<NP, SRC, 2, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
     }
@@ -912,8 +949,16 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             // columns per lane by the lanes a strip wastes
             const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
             const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
-            const int NC = (K3_FEATURISE_NC4 && w4 <= w2) ? 4 : 2;
-            const bool vec = NC == 4 ? v4 : v2;
+            // ... or none at all: with the 64-floats-per-store layout the dead column groups of a row's last strip are skipped, so
+            // it computes ceil(N / 64) groups per row pair where the vector layouts compute whole strips (N = 140: 3 against 4,
+            // 342 against 376 us at 2^25 pairs) -- taken where that saves more than the ~15 % its dword stores cost
+            const long long gn = (N + 63) / 64, gv = std::min(w4, w2) / 64;
+            const bool prefer_scalar = gn * 115 < gv * 100;
+            int NC = (K3_FEATURISE_NC4 && w4 <= w2) ? 4 : 2;
+            const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
+            // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
+            // 257 / 267; two groups, N = 101: 338 / 310)
+            if (!vec) NC = (K3_FEATURISE_NC4 && gn > 2) ? 4 : 2;
             const bool m16 = vec && NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
             // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
             // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
