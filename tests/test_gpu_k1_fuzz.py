@@ -1,4 +1,4 @@
-"""Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, fixed-A flat, row-tile, row-phase) against its two simple kernels
+"""Seeded differential fuzz of K1's fast kernels (pattern, flat pattern, fixed-A flat, row-tile, row-phase, flat CA-trace) against its two simple kernels
 (slot-decode for A = 15, element-per-lane otherwise): random shapes, row ranges, compact / in-place outputs, chunk
 counts per workgroup and both square-root modes; outputs sit inside sentinel-filled buffers; every eighth trial is also
 held to the reference's formula evaluated by ATen on the device (an implementation that shares nothing with the kernels).
@@ -38,6 +38,10 @@ def test_k1_fast_kernels_differential_fuzz():
                 N = 16 * int(rng.integers(1, nmax // 16 + 1))     # aligned lengths: one alignment phase only
             elif A in (1, 3, 5) and trial % 3 == 1:
                 N = 4 * int(rng.integers(4, nmax // 4 + 1))       # N % 4 == 0
+            ca_flat = A == 1 and trial % 2 == 0                    # the flat CA-trace kernel: 8 .. 255 residues, full matrices, larger batches
+            if ca_flat:
+                N = int(rng.integers(8, 256))
+                B = int(rng.integers(1, 60)) if N < 64 else B
             g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
             xyz = torch.randn(B, N, A, 3, generator=g) * float(rng.choice([1.0, 10.0]))
             mask = torch.rand(B, N, A, generator=g) < float(rng.choice([0.5, 0.9, 1.0]))
@@ -60,7 +64,7 @@ def test_k1_fast_kernels_differential_fuzz():
             _lib.set_tuning("k1_jt", int(rng.choice([0, 16, 32, 64, 128])))
             r0 = int(rng.integers(0, N))
             r1 = int(rng.integers(r0 + 1, N + 1))
-            if trial % 3 == 0:
+            if trial % 3 == 0 or ca_flat:
                 r0, r1 = 0, N
             compact = bool(rng.integers(0, 2))
             rows = (r1 - r0) if compact else N
