@@ -151,7 +151,7 @@ typedef struct ps_k1_plan {
     int struct_size;            /* in: sizeof(ps_k1_plan) */
     int n_launches;             /* 0 (empty input) or 1 (every kernel writes both planes in one launch) */
     char family[48];            /* "pattern" | "flat" | "slot_decode" (A = 15); "rowtile" | "rowphase" | "flatA" |
-                                   "ca_flat" | "element" (other atom counts); "empty"; a second launch would be appended with " + " */
+                                   "ca_flat" | "small_flat" | "element" (other atom counts); "empty"; a second launch would be appended with " + " */
     char kernel[96];            /* kernel name with its leading template argument, e.g. "k1_pairdist_a15_pat<32>" */
     unsigned n_workgroups;      /* grid of the first launch */
     unsigned lds_bytes;         /* static + dynamic LDS per workgroup of the first launch */

@@ -1531,6 +1531,95 @@ __global__ __launch_bounds__(256) void k1_pairdist_ca_flat(const float* __restri
     }
 }
 
+// ---- short chains of a few atoms per residue (backbone / CA+CB peptides in large batches) ----
+// The flat idea of k1_pairdist_ca_flat for 2 <= A <= 13: where a row run (N * A * A elements) is a few hundred bytes the
+// row-phase and row-tile kernels spend their time on per-row and per-workgroup set-up (A = 3, N = 16: 2.2 TB/s; A = 4, N = 16:
+// 2.8; profiles/r04_k1_n_sweep_small_a_short.log).  The (B, N, N, A, A) output is one flat run of 16-byte slots, a workgroup owns
+// CA_CS consecutive slots and stages the atoms of the structures they belong to; a lane decodes its slot's first element into
+// (structure, i, j, a, c) with four reciprocal multiplications and steps through the other three by increment-and-carry.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k1_pairdist_small_flat(const float* __restrict__ xyz, const uint8_t* __restrict__ amask,
+                                                              float* __restrict__ dist, uint8_t* __restrict__ dmask, int B,
+                                                              int N, int A, unsigned rcpS, unsigned rcpR, unsigned rcpAA,
+                                                              unsigned rcpA) {
+    extern __shared__ __attribute__((aligned(16))) char smem_sf[];
+    float4* sat = reinterpret_cast<float4*>(smem_sf);                   // [structures of this workgroup][N][A]
+    const int tid = threadIdx.x;
+    const unsigned AA = (unsigned)A * (unsigned)A, R = (unsigned)N * AA, S = (unsigned)N * R;   // elements of a pair / row / structure
+    const unsigned long long total = (unsigned long long)B * S;
+    const unsigned long long e_lo = (unsigned long long)blockIdx.x * (4ull * CA_CS);
+    const unsigned long long e_hi = min(e_lo + 4ull * CA_CS, total);
+    const unsigned b_lo = (unsigned)(e_lo / S), b_hi = (unsigned)((e_hi - 1) / S);
+    const unsigned NA = (unsigned)N * (unsigned)A, n_at = (b_hi - b_lo + 1u) * NA;   // atoms to stage: one contiguous range of xyz
+    {
+        const float* g = xyz + (size_t)b_lo * NA * 3;
+        float* l = reinterpret_cast<float*>(sat);
+        for (unsigned f = tid; f < n_at * 3u; f += 256u) {
+            const unsigned at = f / 3u, comp = f - at * 3u;
+            l[at * 4u + comp] = g[f];
+        }
+        const uint8_t* gm = amask ? amask + (size_t)b_lo * NA : nullptr;
+        for (unsigned at = tid; at < n_at; at += 256u)
+            reinterpret_cast<uint32_t*>(sat)[at * 4u + 3u] = gm ? (gm[at] != 0 ? 1u : 0u) : 1u;
+    }
+    __syncthreads();
+    const unsigned rel0 = (unsigned)(e_lo - (unsigned long long)b_lo * S);   // < S
+    const run16 rund(dist + e_lo), runm(dmask + e_lo);                  // (only used when the plane is requested)
+    const bool wd = dist != nullptr, wm = dmask != nullptr;
+    const char* base = reinterpret_cast<const char*>(sat);
+    const unsigned A16 = (unsigned)A * 16u, NA16 = NA * 16u;
+#pragma unroll 2
+    for (int k = 0; k < CA_K; ++k) {
+        const unsigned sl = (unsigned)k * 256u + (unsigned)tid;         // slot within the workgroup's run
+        const unsigned long long e0 = e_lo + 4ull * sl;
+        if (e0 >= e_hi) break;
+        // first element: rel = element index relative to structure b_lo (< 4 CS + S: 32 bits); quotients by floor(2^32 / d)
+        // and one correction (rel < 2^28)
+        const unsigned rel = rel0 + 4u * sl;
+        unsigned bl = __umulhi(rel, rcpS), r = rel - bl * S;
+        if (r >= S) ++bl, r -= S;
+        unsigned i = __umulhi(r, rcpR), r2 = r - i * R;
+        if (r2 >= R) ++i, r2 -= R;
+        unsigned j = __umulhi(r2, rcpAA), r3 = r2 - j * AA;
+        if (r3 >= AA) ++j, r3 -= AA;
+        unsigned a = __umulhi(r3, rcpA), c = r3 - a * (unsigned)A;
+        if (c >= (unsigned)A) ++a, c -= (unsigned)A;
+        unsigned row = ((bl * (unsigned)N + i) * (unsigned)A + a) * 16u, col = ((bl * (unsigned)N + j) * (unsigned)A + c) * 16u;   // LDS byte offsets
+        float v[4];
+        uint32_t mw = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 xi = *reinterpret_cast<const float4*>(base + row);
+            const float4 xj = *reinterpret_cast<const float4*>(base + col);
+            v[q] = dist_pp<EXACT>(xi, make_float4(xj.x, xj.y, xj.z, 0.f));
+            mw |= (__float_as_uint(xi.w) & __float_as_uint(xj.w)) << (8 * q);
+            // next element: c + 1, carrying into a (next row atom, column atoms start over), j (next column residue), i (next
+            // row residue, column residues start over) and the structure (both atoms move on to the next structure's first)
+            ++c; col += 16u;
+            if (c == (unsigned)A) {
+                c = 0; col -= A16; ++a; row += 16u;
+                if (a == (unsigned)A) {
+                    a = 0; row -= A16; ++j; col += A16;
+                    if (j == (unsigned)N) {
+                        j = 0; col -= NA16; ++i; row += A16;
+                        if (i == (unsigned)N) { i = 0; col += NA16; }
+                    }
+                }
+            }
+        }
+        if (e0 + 4ull <= e_hi) {
+            if (wd) rund.store(16u * sl, 0u, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                        __float_as_uint(v[3])));
+            if (wm) runm.store4(4u * sl, 0u, mw);
+        } else {   // the last slot of the whole output (B * N * N * A * A is not a multiple of 4)
+            for (int q = 0; q < (int)(e_hi - e0); ++q) {
+                if (wd) dist[e0 + q] = v[q];
+                if (wm) dmask[e0 + q] = (uint8_t)((mw >> (8 * q)) & 1u);
+            }
+        }
+    }
+}
+
 // ---- generic A: one output element per lane, runtime decode, scalar stores ----
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k1_pairdist_generic(const float* __restrict__ xyz,
@@ -1770,6 +1859,20 @@ bool ca_flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, i
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
+// Short chains of 2 .. 13 atoms per residue, full matrices: the flat kernel above up to the length where the row kernels catch up
+// (same-box sweeps, TB/s flat / row kernel, profiles/r04_k1_n_sweep_small_a_short.log: A = 2 N = 8 4.7 / 0.7, 32 5.7 / 4.8, 64 5.8 /
+// 5.8, 128 5.6 / 5.9; A = 3 N = 16 4.9 / 2.3, 64 5.1 / 4.7, 128 4.5 / 5.2; A = 4 N = 16 5.8 / 3.1, 64 5.7 / 5.4, 128 4.7 / 6.0;
+// A = 5 N = 8 4.9 / 2.0, 16 5.1 / 4.1, 32 5.2 / 5.1, 64 4.7 / 6.1; A = 8 N = 8 5.8 / 3.7, 16 5.9 / 6.4; A = 13 N = 4 5.1 / 2.6,
+// 16 5.2 / 4.4, 24 4.8 / 6.6).  cfg.rowphase = 1 keeps the row-phase / row-tile kernels (A/B runs).
+inline int small_flat_max_n(int A) { return A <= 4 ? 64 : A == 5 ? 31 : A == 6 ? 24 : A == 7 ? 20 : A == 8 ? 8 : 16; }
+bool small_flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int row_begin, int row_end,
+                         int out_rows, int out_row_origin) {
+    if (A < 2 || A > 13 || g.variant != 0 || g.flat != 1 || (g.rowphase & 15) != 0) return false;
+    if (N < 2 || N > small_flat_max_n(A)) return false;
+    if (row_begin != 0 || row_end != N || out_rows != N || out_row_origin != 0) return false;
+    return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
+}
+
 template <int ACT>
 int launch_rowphase(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* dist, uint8_t* dmask, int B, int N,
                     int A, int row_begin, int row_end, int out_rows, int out_row_origin, const K1Go& go) {
@@ -1906,6 +2009,20 @@ int k1_dispatch(const K1Go& go, const float* xyz, const uint8_t* atom_mask, floa
     }
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     const int rows = row_end - row_begin;
+    if (small_flat_eligible(g, dist, dist_mask, B, N, A, row_begin, row_end, out_rows, out_row_origin)) {
+        const unsigned S = (unsigned)N * N * A * A;
+        const unsigned long long total = (unsigned long long)B * S;
+        const unsigned long long n_wg = (total + 4ull * CA_CS - 1) / (4ull * CA_CS);
+        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        const size_t lds = (size_t)((4 * CA_CS + S - 1) / S + 1) * N * A * sizeof(float4);   // the structures a workgroup's slots can touch
+        auto rcp = [](unsigned d) { return d == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / d); };
+        const unsigned rcpS = rcp(S), rcpR = rcp((unsigned)N * A * A), rcpAA = rcp((unsigned)A * A), rcpA = rcp((unsigned)A);
+        if (g.exact_sqrt)
+            return k1_go(go, "small_flat", "k1_pairdist_small_flat", A, k1_pairdist_small_flat<true>, dim3((unsigned)n_wg), dim3(256),
+                         lds, xyz, atom_mask, dist, dist_mask, B, N, A, rcpS, rcpR, rcpAA, rcpA);
+        return k1_go(go, "small_flat", "k1_pairdist_small_flat", A, k1_pairdist_small_flat<false>, dim3((unsigned)n_wg), dim3(256),
+                     lds, xyz, atom_mask, dist, dist_mask, B, N, A, rcpS, rcpR, rcpAA, rcpA);
+    }
     if (rowtile_eligible(g, dist, dist_mask, A)) {
         if (A == 4)
             return launch_rowtile<4>(g, xyz, atom_mask, dist, dist_mask, B, N, row_begin, row_end, out_rows, out_row_origin, go);

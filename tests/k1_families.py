@@ -27,17 +27,19 @@ FAMILY_SHAPES = [
     (2, 19, 16, (2, 19), True, {}, "flatA"),
     (2, 35, 15, None, False, {"k1_flat": 4}, "flatA"),
     # row-tile kernels of A = 4, 8
-    (2, 40, 4, None, False, {}, "rowtile"),
+    (2, 129, 4, None, False, {}, "rowtile"),
     (2, 33, 8, (1, 32), False, {}, "rowtile"),
     # row-phase kernel (round 3): every other atom count up to 13, any length
     (3, 501, 1, None, False, {}, "rowphase"),
     (3, 33, 1, (2, 30), False, {}, "rowphase"),
     (4, 100, 1, None, False, {"k1_rowphase": 1}, "rowphase"),
-    (2, 18, 2, None, False, {}, "rowphase"),
+    (2, 200, 2, None, False, {}, "rowphase"),
+    (2, 18, 2, (3, 18), False, {}, "rowphase"),
     (2, 21, 5, (4, 20), True, {}, "rowphase"),
     (2, 40, 7, None, False, {}, "rowphase"),
     (1, 30, 13, None, False, {}, "rowphase"),
-    (2, 6, 3, None, False, {}, "rowphase"),
+    (2, 100, 3, None, False, {}, "rowphase"),
+    (2, 6, 3, None, False, {"k1_rowphase": 1}, "rowphase"),
     # ... and, through its run-time atom-count instantiations (even / odd), every other count up to 64
     (2, 40, 20, None, False, {}, "rowphase"),
     (2, 17, 33, (0, 9), True, {}, "rowphase"),
@@ -50,10 +52,16 @@ FAMILY_SHAPES = [
     (3, 33, 1, None, False, {}, "ca_flat"),
     (40, 9, 1, None, False, {}, "ca_flat"),
     (2, 255, 1, None, False, {}, "ca_flat"),
+    # short chains of 2 .. 13 atoms per residue (up to 64 residues at A <= 4, 16 at A >= 9), full matrices (round 4): the generic flat kernel
+    (2, 18, 2, None, False, {}, "small_flat"),
+    (5, 6, 3, None, False, {}, "small_flat"),
+    (3, 16, 4, None, False, {}, "small_flat"),
+    (2, 3, 13, None, False, {}, "small_flat"),
+    (7, 2, 5, None, False, {}, "small_flat"),
     # element-per-lane kernel: A > 64, or nothing else eligible (N < 16 without the row-phase kernel; the simple variant)
     (1, 8, 70, None, False, {}, "element"),
     (2, 10, 20, None, False, {"k1_rowphase": 2}, "element"),
     (2, 40, 7, None, False, {"k1_variant": 1}, "element"),
 ]
 
-ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "ca_flat", "element"}
+ALL_FAMILIES = {"pattern", "flat", "slot_decode", "flatA", "rowtile", "rowphase", "ca_flat", "small_flat", "element"}
