@@ -88,7 +88,7 @@ typedef struct ps_k1_config {
     int flat_fl_log2;     /* A = 15 flat pattern kernel: log2(pairs per chunk), 4..7; 0 = the default, 6 (64 pairs, 72 KB per chunk) */
     int rowphase;         /* [diagnostic] row-phase kernel (atom counts up to 64 other than 4, 8): 0 (default) where it is the default
                              dispatch -- every count up to 64 without a row-tile or fixed-A flat kernel, short chains excepted (A = 1, 8..255
-                             residues; 2 <= A <= 13 up to 16..64 residues; full matrices): they take the two flat kernels; 1 also for A = 14, 15, 16, 24, 32 and
+                             residues; 2 <= A <= 16 up to 7..64 residues; full matrices): they take the two flat kernels; 1 also for A = 14, 15, 16, 24, 32 and
                              for those CA traces (A/B runs); 2 never (fixed-A flat / element kernels instead).  Bits 4..7 (value / 16) are A/B
                              switches of that kernel: 16 = the A = 1 seam slots written element-wise from both rows (round 3) */
     int experiment;       /* [diagnostic] must be 0 in the product library; timing experiments exist only in builds made with

@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(256) void k1_pairdist_ca_flat(const float* __restri
 }
 
 // ---- short chains of a few atoms per residue (backbone / CA+CB peptides in large batches) ----
-// The flat idea of k1_pairdist_ca_flat for 2 <= A <= 13: where a row run (N * A * A elements) is a few hundred bytes the
+// The flat idea of k1_pairdist_ca_flat for 2 <= A <= 16: where a row run (N * A * A elements) is a few hundred bytes the
 // row-phase and row-tile kernels spend their time on per-row and per-workgroup set-up (A = 3, N = 16: 2.2 TB/s; A = 4, N = 16:
 // 2.8; profiles/r04_k1_n_sweep_small_a_short.log).  The (B, N, N, A, A) output is one flat run of 16-byte slots, a workgroup owns
 // CA_CS consecutive slots and stages the atoms of the structures they belong to; a lane decodes its slot's first element into
@@ -1859,15 +1859,16 @@ bool ca_flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, i
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));
 }
 
-// Short chains of 2 .. 13 atoms per residue, full matrices: the flat kernel above up to the length where the row kernels catch up
+// Short chains of 2 .. 16 atoms per residue, full matrices: the flat kernel above up to the length where the row kernels catch up
 // (same-box sweeps, TB/s flat / row kernel, profiles/r04_k1_n_sweep_small_a_short.log: A = 2 N = 8 4.7 / 0.7, 32 5.7 / 4.8, 64 5.8 /
 // 5.8, 128 5.6 / 5.9; A = 3 N = 16 4.9 / 2.3, 64 5.1 / 4.7, 128 4.5 / 5.2; A = 4 N = 16 5.8 / 3.1, 64 5.7 / 5.4, 128 4.7 / 6.0;
 // A = 5 N = 8 4.9 / 2.0, 16 5.1 / 4.1, 32 5.2 / 5.1, 64 4.7 / 6.1; A = 8 N = 8 5.8 / 3.7, 16 5.9 / 6.4; A = 13 N = 4 5.1 / 2.6,
 // 16 5.2 / 4.4, 24 4.8 / 6.6).  cfg.rowphase = 1 keeps the row-phase / row-tile kernels (A/B runs).
-inline int small_flat_max_n(int A) { return A <= 4 ? 64 : A == 5 ? 31 : A == 6 ? 24 : A == 7 ? 20 : A == 8 ? 8 : 16; }
+// (A = 14 .. 16, TB/s flat / row-phase: N = 4 5.2-5.8 / 3.3-4.0, N = 8 .. 15 within 5 % of each other: up to seven residues)
+inline int small_flat_max_n(int A) { return A <= 4 ? 64 : A == 5 ? 31 : A == 6 ? 24 : A == 7 ? 20 : A == 8 ? 8 : A <= 13 ? 16 : 7; }
 bool small_flat_eligible(const K1Cfg& g, const float* dist, const uint8_t* dmask, int B, int N, int A, int row_begin, int row_end,
                          int out_rows, int out_row_origin) {
-    if (A < 2 || A > 13 || g.variant != 0 || g.flat != 1 || (g.rowphase & 15) != 0) return false;
+    if (A < 2 || A > 16 || g.variant != 0 || g.flat != 1 || (g.rowphase & 15) != 0) return false;
     if (N < 2 || N > small_flat_max_n(A)) return false;
     if (row_begin != 0 || row_end != N || out_rows != N || out_row_origin != 0) return false;
     return !((reinterpret_cast<uintptr_t>(dist) & 15) || (reinterpret_cast<uintptr_t>(dmask) & 15));

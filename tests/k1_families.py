@@ -52,7 +52,9 @@ FAMILY_SHAPES = [
     (3, 33, 1, None, False, {}, "ca_flat"),
     (40, 9, 1, None, False, {}, "ca_flat"),
     (2, 255, 1, None, False, {}, "ca_flat"),
-    # short chains of 2 .. 13 atoms per residue (up to 64 residues at A <= 4, 16 at A >= 9), full matrices (round 4): the generic flat kernel
+    # short chains of 2 .. 16 atoms per residue (up to 64 residues at A <= 4, 16 at A = 9 .. 13, 7 at 14 .. 16), full matrices (round 4):
+    # the generic flat kernel
+    (3, 5, 15, None, False, {}, "small_flat"),
     (2, 18, 2, None, False, {}, "small_flat"),
     (5, 6, 3, None, False, {}, "small_flat"),
     (3, 16, 4, None, False, {}, "small_flat"),
