@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                     return rowmask[ri >> 1] >> (8u * (ri & 1u));
                 };
                 // one 16-byte group of one plane: 16 bits of the column mask from column j on (zero beyond N), AND the row's
-                // bit; where the group runs into row i + 1 (N >= 100: at most once), that row's first columns
+                // bit; where the group runs into row i + 1 (N >= 64: at most once), that row's first columns
                 auto group = [&](const uint32_t* W, uint32_t bit, uint32_t w0, uint32_t w1, unsigned j, bool wrap) {
                     const unsigned k = j >> 5, sh = j & 31u;
                     uint32_t x = (w0 & bit) ? (__builtin_amdgcn_alignbit(W[k + 1], W[k], sh) & 0xFFFFu) : 0u;
@@ -830,6 +830,9 @@ inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63)
 // strip idle (N = 64: 143 us against 93 for the one-column kernel at 2^25 pairs; N = 16: 1427 against 282;
 // profiles/r04_k3_shapes.log) -- short chains stay with the one-column kernel.
 constexpr int K3_SWEEP_MIN_N = 100;
+// ... the featuriser's sweep (tasks of two rows, a structure's column points in LDS, two workgroups per CU) pays from 64 on:
+// same-box trace at 2^25 pairs, sweep / one-column kernel: N = 99 314 / 361 us, 80 344 / 365, 64 280 / 300, 48 387 / 354, 33 645 / 474
+constexpr int K3_FEATURISE_MIN_N = 64;
 constexpr int K3_SMALL_MAX_N = 32;    // k3_small: one wave per structure (33..64 measured: no better than the one-column kernel)
 
 template <int NP, int SRC>
@@ -934,7 +937,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
     if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || exact_angles < 0 || exact_angles > 2)
         return (int)hipErrorInvalidValue;
     if (B == 0 || N == 0) return 0;
-    if (exact_angles == 0) {   // the per-CU sweep: any N >= K3_SWEEP_MIN_N whose rows fit in LDS
+    if (exact_angles == 0) {   // the per-CU sweep: any N >= K3_FEATURISE_MIN_N whose rows fit in LDS
         uintptr_t alf = 0, alm = 0;
         for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
                               (const void*)theta, (const void*)phi})
@@ -944,7 +947,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
         // one structure's rows (points + mask words), its column points, its column masks (bytes or bit sets)
         const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
                             std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
-        if (N >= K3_SWEEP_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
+        if (N >= K3_FEATURISE_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
             // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
             // columns per lane by the lanes a strip wastes
             const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;

@@ -1697,11 +1697,11 @@ def test_inter_residue_geometry_golden(SB):
             assert_close(v, g[k], bad_frac=1.0 / g[k].numel())
 
 
-# 34: below the per-CU sweep (one-column kernel); 256, 512: four columns per lane, vector stores, strip-local 16-byte mask
+# 34, 63: below the per-CU sweep (one-column kernel); 64, 77: its shortest chains (one live column group of two); 256, 512: four columns per lane, vector stores, strip-local 16-byte mask
 # stores; 208: the same with a partial last strip (13 of 16 column groups live); 200, 500: four columns, vector float stores,
 # flat mask stores; 258, 100: two columns per lane (vector); 101, 129: odd, two columns, 64-floats-per-store layout; 301: the
 # same with three strips; 511, 257: odd, four columns
-@pytest.mark.parametrize("N", [100, 101, 258, 34, 256, 200, 208, 512, 129, 301, 257, 511, 500])
+@pytest.mark.parametrize("N", [100, 101, 258, 34, 256, 200, 208, 512, 129, 301, 257, 511, 500, 64, 77, 63])
 def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     """The fused featuriser must equal the K1 slices -- in BOTH square-root modes of the device (it takes the mode K1
     takes: the hardware square root by default, the correctly rounded one after set_exact_sqrt(True)), the two modes
@@ -1778,12 +1778,12 @@ def _featuriser_in_sentinels(xyz, mask, shifts, exact_sqrt=0):
 
 
 def test_inter_residue_geometry_differential_fuzz(SB):
-    """Random lengths (100 .. 700: one to three strips, every residue of the length modulo 16), batch sizes, masks and plane
+    """Random lengths (64 .. 700: one to three strips, every residue of the length modulo 16), batch sizes, masks and plane
     placements: the per-CU featuriser (vector / 64-floats-per-store float planes, strip-local / flat mask stores, one or
     two workgroups per CU) against the one-column kernel, bit for bit, inside sentinels."""
     rng = torch.Generator().manual_seed(20241004)
     for trial in range(36):
-        N = int(torch.randint(100, 701, (1,), generator=rng))
+        N = int(torch.randint(64, 701, (1,), generator=rng))
         if trial % 6 == 0:
             N = (N // 16) * 16                   # the strip-local mask form
         B = int(torch.randint(1, 5, (1,), generator=rng)) if N > 200 else int(torch.randint(1, 40, (1,), generator=rng))
