@@ -465,8 +465,9 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
 //   * VEC: the lane's NC columns are consecutive and every float plane goes out in 4 * NC-byte stores (N % NC == 0, planes
 //     4 * NC-byte aligned).  !VEC (any N, any 4-byte alignment): the columns are 64 apart and a store instruction writes 64
 //     consecutive floats of a row, as in k3_sweep.
-//   * M16 (VEC, NC = 4, N % 16 == 0, 16-byte aligned mask planes): the mask planes have their own lane map inside a strip:
-//     a lane owns 16 consecutive column residues of one row, a store instruction carries four rows x 256 bytes.
+//   * M16 (VEC, N % 16 == 0, 16-byte aligned mask planes): the mask planes have their own lane map inside a strip:
+//     a lane owns 16 consecutive column residues of one row, a store instruction carries four rows x 256 bytes (NC = 2:
+//     up to eight rows x 128).
 //     !M16: the mask planes are written FLAT.  The mask bytes of a task's rows are one contiguous run of every plane
 //     (rows are contiguous in memory), whatever N is; the run is cut on the plane's absolute 16-byte grid -- a group that
 //     starts in the task's rows belongs to the task, also where it runs into the next task's first row -- and a lane
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
     int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
-    static_assert(!M16 || (NC == 4 && VEC), "16-byte strip mask stores ride on the four-column vector kernel");
+    static_assert(!M16 || VEC, "16-byte strip mask stores ride on the vector kernels");
     constexpr int POL = WT ? 16 : 0;
     extern __shared__ __attribute__((aligned(16))) f32x2 k3_rowbuf[];   // [row pair][N, CA, CB][xyz]; then the row mask words, the column points, the column masks
     __shared__ unsigned next_task;
@@ -588,7 +589,8 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                                      r_th = rs(theta + seg), r_ph = rs(phi + seg);
         const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + (M16 ? seg : sbase)), r_mcb = rs(m_cb + (M16 ? seg : sbase)),
                                      r_mno = rs(m_no + (M16 ? seg : sbase));
-        const int gq = lane & 15, rq = lane >> 4;                 // M16: this lane's 16-column group and row of a 4-row store
+        constexpr int GS = 4 * NC, RS = 64 / GS;                  // M16: 16-column groups of a strip, rows of a store instruction (4 / 8)
+        const int gq = lane % GS, rq = lane / GS;                 // ... this lane's group and row
         int c = c_lo + wave;
         while (c < c_hi) {
             const int chunk = c / tpc, strip0 = c - chunk * tpc;
@@ -692,13 +694,13 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
                 }
                 const bool live = lv[0];
                 const int lane_off = jbase * 4;
-                if constexpr (M16) {                              // the strip's mask planes: four rows per store instruction
+                if constexpr (M16) {                              // the strip's mask planes: four (NC = 2: eight) rows per store instruction
                     const int jg = strip * 64 * NC + 16 * gq;
                     if (jg < N) {                                 // N % 16 == 0: a group is in or out
                         const k3_u32x4 cm_ca = *reinterpret_cast<const k3_u32x4*>(colmask + jg);
                         const k3_u32x4 cm_cb = *reinterpret_cast<const k3_u32x4*>(colmask + N + jg);
                         const k3_u32x4 cm_o = *reinterpret_cast<const k3_u32x4*>(colmask + 2 * N + jg);
-                        for (int k4 = i0; k4 < i1; k4 += 4) {
+                        for (int k4 = i0; k4 < i1; k4 += RS) {
                             const int rr = k4 + rq;
                             if (rr < i1) {
                                 const uint32_t w = rowmask[rr >> 1] >> (8 * (rr & 1));
@@ -962,7 +964,7 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
             // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
             // 257 / 267; two groups, N = 101: 338 / 310)
             if (!vec) NC = (K3_FEATURISE_NC4 && gn > 2) ? 4 : 2;
-            const bool m16 = vec && NC == 4 && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
+            const bool m16 = vec && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
             // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
             // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
             const bool wt = m16 && N % 128 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;
@@ -998,7 +1000,9 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                                  d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
                                  (unsigned)n_tasks, tasks_per_wg, rcpN);
             };
-            static unsigned long long prep[12][1] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+            static unsigned long long prep[16][1] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
+            if (wt && NC == 2) return exact_sqrt ? go(k3_featurise<true, 2, true, true, true>, prep[12]) : go(k3_featurise<false, 2, true, true, true>, prep[13]);
+            if (m16 && NC == 2) return exact_sqrt ? go(k3_featurise<true, 2, true, true, false>, prep[14]) : go(k3_featurise<false, 2, true, true, false>, prep[15]);
             if (wt) return exact_sqrt ? go(k3_featurise<true, 4, true, true, true>, prep[0]) : go(k3_featurise<false, 4, true, true, true>, prep[1]);
             if (m16) return exact_sqrt ? go(k3_featurise<true, 4, true, true, false>, prep[2]) : go(k3_featurise<false, 4, true, true, false>, prep[3]);
             if (NC == 4 && vec) return exact_sqrt ? go(k3_featurise<true, 4, true, false, false>, prep[4]) : go(k3_featurise<false, 4, true, false, false>, prep[5]);
