@@ -306,6 +306,9 @@ int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, in
  * (bit-identical to K1 with exact_sqrt = 1).
  * exact_angles (ABI 4): omega, theta and phi in the arithmetic ps_pairwise_angles_f32 uses for the same value (0 fast,
  * 1 the reference's order of operations): the three planes equal the corresponding K3 launches bit for bit in both modes.
+ * Placement of the nine planes: any 4-byte (fp32) / 1-byte (mask) boundary, each plane its own; results do not depend on
+ * it.  Fastest where every plane starts on a 16-byte boundary (vector stores; the three mask planes then share one 16-byte
+ * grid) -- protstruc_amd.ops pads the plane stride accordingly.  N * N < 2^31.
  */
 int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
                                   float* d_ca, float* d_cb, float* d_no,
