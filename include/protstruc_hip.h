@@ -78,7 +78,9 @@ typedef struct ps_k1_config {
     int rows_per_block;   /* pattern kernel: residue rows per workgroup, 1..32 (default 1, which for chains shorter than 64
                              residues means ceil(64 / N) rows); row-phase kernel: rows per lane when > 1 (default: 12 / 16 / 24
                              by atom count); row-tile kernel: rows per workgroup when > 1 (default 6) */
-    int lds_pad_kb;       /* pattern kernel: idle LDS per workgroup (caps resident workgroups per CU), 0..120 (default 20) */
+    int lds_pad_kb;       /* pattern kernel: KB of idle LDS per workgroup (caps resident workgroups per CU), 0..120; -1 (default): by chain
+                             length -- 36 KB (3 workgroups per CU) from 256 residues on, 20 KB (5 per CU) below: eight boxes of round 4,
+                             B=64, N=512: 36 KB 1.5-3.8 % ahead of 20 KB on seven; one box, N = 256 .. 2048 +2-3 %, N = 128 even, N <= 64 -7 % */
     int flat_cpw;         /* flat kernels: consecutive chunks per workgroup, 1..64 (default 1) */
     int flat_lds_pad_kb;  /* flat pattern kernel: idle LDS per workgroup, 0..100 */
     int jt;               /* pattern kernel: column residues per tile, 16 / 32 / 64 / 128, 0 = the default (32; 128 for a launch

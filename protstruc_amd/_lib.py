@@ -137,7 +137,7 @@ def check(code, what):
 # changes a knob can never tear the configuration another thread is launching with.
 _K1_KEYS = {   # tuning key -> (struct field, lowest, highest)
     "k1_exact_sqrt": ("exact_sqrt", 0, 1), "k1_variant": ("variant", 0, 1), "k1_flat": ("flat", 0, 4),
-    "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", 0, 120),
+    "k1_rows_per_block": ("rows_per_block", 1, 32), "k1_lds_pad_kb": ("lds_pad_kb", -1, 120),
     "k1_flat_cpw": ("flat_cpw", 1, 64), "k1_flat_lds_pad_kb": ("flat_lds_pad_kb", 0, 100),
     "k1_jt": ("jt", 0, 128), "k1_xcd_remap": ("xcd_remap", 0, 1), "k1_store_nt": ("store_nt", 0, 1),
     "k1_flat_fl_log2": ("flat_fl_log2", 0, 7), "k1_rowphase": ("rowphase", 0, 255), "k1_experiment": ("experiment", 0, 31),

@@ -1726,7 +1726,7 @@ int launch_a15(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* di
         // LDS: padded float4 images of the JT column and IR row residues, then the two mask bit streams (at most
         // (JT * 15 / 256 + 1) * 8 + (IR * 15 / 256 + 1) * 8 + 1 words, which JT + 4 + IR words always cover for JT >= 32)
         const size_t lds_pat = (size_t)(JT + IR) * RS * sizeof(float4) + (size_t)(JT + 4 + IR) * sizeof(uint32_t) +
-                               (size_t)g.lds_pad_kb * 1024;
+                               (size_t)(g.lds_pad_kb >= 0 ? g.lds_pad_kb : (N >= 256 ? 36 : 20)) * 1024;   // -1 = by chain length, see ps_k1_config
         const unsigned long long n_wg = (unsigned long long)grid.x * grid.y * grid.z;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
         const int remap = (g.xcd_remap && n_wg % 8 == 0 && n_wg >= 64) ? 1 : 0;
@@ -1964,7 +1964,7 @@ int launch_flatA(const K1Cfg& g, const float* xyz, const uint8_t* amask, float* 
 bool cfg_valid(const K1Cfg& g) {
     if (g.struct_size != (int)sizeof(K1Cfg)) return false;
     if (g.variant < 0 || g.variant > 1 || g.flat < 0 || g.flat > 4 || g.flat == 3) return false;
-    if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < 0 || g.lds_pad_kb > 120) return false;
+    if (g.rows_per_block < 1 || g.rows_per_block > 32 || g.lds_pad_kb < -1 || g.lds_pad_kb > 120) return false;
     if (g.flat_cpw < 1 || g.flat_cpw > 64 || g.flat_lds_pad_kb < 0 || g.flat_lds_pad_kb > 100) return false;
     if (g.jt != 0 && g.jt != 16 && g.jt != 32 && g.jt != 64 && g.jt != 128) return false;
     if (g.flat_fl_log2 != 0 && (g.flat_fl_log2 < 4 || g.flat_fl_log2 > 7)) return false;
@@ -1988,7 +1988,7 @@ extern "C" void ps_k1_config_default(ps_k1_config* cfg) {
     // 20 KB of idle LDS per workgroup of the pattern kernel: with its 32-residue tiles (jt = 0 -> 32) five workgroups are
     // resident per CU; never more than 2 % behind the best configuration on the output buffers of ten boxes
     // (profiles/r03_k1_ab_lean_*.log; the 8 KB + 128-residue tiles of rounds 2-3 are a tuner candidate)
-    cfg->lds_pad_kb = 20;
+    cfg->lds_pad_kb = -1;
     cfg->flat_cpw = 1;
     cfg->xcd_remap = 1;
 }

@@ -149,8 +149,11 @@ _K1_LAUNCH = _k1_launch_entry
 # fast ones, -3 % on others), 6 per CU (16 KB), 3 per CU (36 KB: +1-4 % on slow and medium buffers, -4 % on fast ones), the
 # 16-residue tile, the 64-residue tile and the 128-residue tile + 8 KB that was the default until late round 3
 # (profiles/r03_k1_ab_lean_*.log).
+# Round 4: 36 KB won on seven of eight boxes at B=64, N=512 (1.5-3.8 %; profiles/r04_k1_tuner_tables.log) and is what the
+# library default (-1: by chain length) now takes from 256 residues on; 20 KB stays a candidate.
 _K1_CANDIDATE_PATTERN = (
-    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 0},      # the default: 32-residue tiles, 5 workgroups per CU
+    {"rows_per_block": 1, "lds_pad_kb": -1, "jt": 0},      # the default: 32-residue tiles, idle LDS by chain length (36 KB = 3 workgroups per CU from N = 256, 20 KB = 5 below)
+    {"rows_per_block": 1, "lds_pad_kb": 20, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 24, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 16, "jt": 32},
     {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 32},
@@ -172,7 +175,8 @@ _K1_CANDIDATE_FLAT = (
 
 def _cand_label(c) -> str:
     if "rows_per_block" in c:
-        return f"{c['rows_per_block']}row" + (f"+{c['lds_pad_kb']}KB" if c["lds_pad_kb"] else "") + (f" jt{c['jt']}" if c["jt"] else "")
+        pad = "+autoKB" if c["lds_pad_kb"] < 0 else (f"+{c['lds_pad_kb']}KB" if c["lds_pad_kb"] else "")
+        return f"{c['rows_per_block']}row" + pad + (f" jt{c['jt']}" if c["jt"] else "")
     return f"{c['flat_cpw']}chunk" + (f"+{c['flat_lds_pad_kb']}KB" if c["flat_lds_pad_kb"] else "") + \
         (f" {1 << c['flat_fl_log2']}pairs" if c.get("flat_fl_log2") else "")
 

@@ -53,7 +53,7 @@ def test_python_binding_matches_header(lib_path):
     lib.ps_k1_config_default(ctypes.byref(cfg))
     assert cfg.struct_size == ctypes.sizeof(_lib.K1Config)
     assert (cfg.flat, cfg.rows_per_block, cfg.flat_cpw, cfg.xcd_remap, cfg.exact_sqrt, cfg.experiment) == (1, 1, 1, 1, 0, 0)
-    assert cfg.lds_pad_kb == 20
+    assert cfg.lds_pad_kb == -1          # by chain length: 36 KB from 256 residues on, 20 KB below
 
 
 def test_tuning_is_a_per_device_host_table(lib_path):
@@ -93,7 +93,7 @@ def test_k1_config_is_validated_before_any_launch(lib_path):
     assert call(None) == 0 and call(_lib.k1_config(0)) == 0
     for field, value in [("struct_size", 8), ("struct_size", 0), ("experiment", 2), ("experiment", 1), ("variant", 2),
                          ("flat", 5), ("rows_per_block", 0), ("rows_per_block", 33), ("flat_cpw", 0), ("jt", 96),
-                         ("lds_pad_kb", 121), ("flat_fl_log2", 3), ("flat_fl_log2", 8), ("flat", 3), ("rowphase", 3),
+                         ("lds_pad_kb", 121), ("lds_pad_kb", -2), ("flat_fl_log2", 3), ("flat_fl_log2", 8), ("flat", 3), ("rowphase", 3),
                          ("flat_lds_pad_kb", -1)]:
         assert call(_lib.k1_config(0, **{field: value})) == 1, (field, value)
 
