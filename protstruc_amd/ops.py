@@ -114,8 +114,9 @@ def _on(device: torch.device):
 # ---- optional, per-device choice of K1's output granule per workgroup -----------------------------------------
 # How fast K1's store stream is absorbed depends on the physical memory behind the output buffers (DESIGN.md section 4,
 # "the two classes of allocation": 6.2-7.3 TB/s for the same kernel on different allocations of one process), and so
-# does which launch configuration is the fastest.  The library default (ps_k1_config_default: 32-residue tiles, 20 KB of
-# idle LDS = 5 workgroups per CU) is the configuration that was never more than 2 % behind on the buffers of ten boxes;
+# does which launch configuration is the fastest.  The library default (ps_k1_config_default: 32-residue tiles, idle LDS by
+# chain length -- 36 KB = 3 workgroups per CU from 256 residues on, 20 KB = 5 below) is the configuration that won on seven
+# of eight boxes in round 4 (profiles/r04_k1_tuner_tables.log);
 # nothing is timed behind the caller's back.  The tuner is an explicit call -- ops.autotune_pairwise_distance(), which
 # bench.py makes before its warm-up and reports -- or, with PROTSTRUC_AMD_AUTOTUNE=1 (read at import;
 # ops.set_implicit_autotune at run time), runs on the first large call of each kind per device.  It writes that DEVICE's
