@@ -10,6 +10,7 @@
             (2, 512) through the default dispatch (row-phase kernel)
     k1u     K1 at the unaligned shapes (A, N) = (5, 501), (1, 501), (37, 100) and the aligned (5, 512), ~4 GB each, three
             modes per shape in this order: both planes, distance plane only, mask plane only (read with `pmcseq`)
+    k1f     the flat short-chain kernels of K1, ~4 GB of output each: (A, N) = (1, 128), (1, 16), (3, 16), (4, 32), (13, 8)
     k5      K5 / K6 / K4 at BASELINE config 5's shape (B=256, N=384): diffuse_xyz (in-kernel Philox), diffuse_xyz with
             injected noise, standardize, backbone_orientations, the fused diffuse + frames step
 Every kernel is launched `reps` times (default 10) after 2 warm-ups, nothing else runs on the GPU."""
@@ -93,6 +94,17 @@ elif what == "k1u":
         repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
         repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, want_mask=False))
         repeat(lambda: ops.pairwise_distance(xyz, mask, out_mask=m, want_dist=False))
+        del xyz, mask, d, m
+elif what == "k1f":
+    for A, N in ((1, 128), (1, 16), (3, 16), (4, 32), (13, 8)):
+        B = max(1, int(4e9 / (N * N * A * A * 5)))
+        g2 = torch.Generator().manual_seed(A * 1000 + N)
+        xyz = torch.randn(B, N, A, 3, generator=g2).cuda()
+        mask = (torch.rand(B, N, A, generator=g2) < 0.9).cuda()
+        d = torch.empty(B, N, N, A, A, device="cuda")
+        m = torch.empty(B, N, N, A, A, dtype=torch.bool, device="cuda")
+        print("k1f", A, N, B, _lib.k1_plan(B, N, A), "algorithmic bytes per launch", B * N * N * A * A * 5, flush=True)
+        repeat(lambda: ops.pairwise_distance(xyz, mask, out_dist=d, out_mask=m))
         del xyz, mask, d, m
 elif what == "k1":
     xyz, mask = synth(64, 512)
