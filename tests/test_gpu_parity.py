@@ -1781,8 +1781,10 @@ def test_inter_residue_geometry_differential_fuzz(SB):
     """Random lengths (64 .. 700: one to three strips, every residue of the length modulo 16), batch sizes, masks and plane
     placements: the per-CU featuriser (vector / 64-floats-per-store float planes, strip-local / flat mask stores, one or
     two workgroups per CU) against the one-column kernel, bit for bit, inside sentinels."""
-    rng = torch.Generator().manual_seed(20241004)
-    for trial in range(36):
+    import os
+    # PS_FEAT_FUZZ_SEED / PS_FEAT_FUZZ_TRIALS: one-off longer runs (the committed defaults are what CI runs)
+    rng = torch.Generator().manual_seed(int(os.environ.get("PS_FEAT_FUZZ_SEED", "20241004")))
+    for trial in range(int(os.environ.get("PS_FEAT_FUZZ_TRIALS", "36"))):
         N = int(torch.randint(64, 701, (1,), generator=rng))
         if trial % 6 == 0:
             N = (N // 16) * 16                   # the strip-local mask form
