@@ -37,7 +37,7 @@ extern "C" {
 #define PS_RNG_STATE_WORDS 528
 
 /* ABI version of this header (bumped on any signature change); ps_abi_version() returns the library's. */
-#define PS_ABI_VERSION 4
+#define PS_ABI_VERSION 5
 int ps_abi_version(void);
 
 /* 0 for the product library.  1 for builds made with -DPS_EXPERIMENTS (tools/ only), which contain timing
@@ -193,16 +193,21 @@ int ps_backbone_dihedrals_f32(const float* xyz, const float* chain_idx,
  * where p_k = xyz[b][ src[k] ? j : i ][ atom[k] ].  Rows i in
  * [row_begin, row_end) are produced into an (B, out_rows, N) buffer with the same
  * row addressing as K1.
- * exact_angles (ABI 4), the angle counterpart of ps_k1_config.exact_sqrt:
- *   0  the fast arithmetic: triple-product dihedral with one reciprocal square root, polynomial atan2 / acos, cosine
- *      through v_rsq_f32 -- exact where the reference is exact (+0 diagonal, NaN positions), otherwise within the
- *      conditioning gates of SURVEY hard part 3 (3.8e-6 of off-diagonal dihedrals more than 1e-5 from the reference
- *      at unit scale, max 6.5e-5; profiles/r04_k3_error_stats.log);
- *   1  the reference's order of operations (geometry.py:110-124, :64-66): three cross products, y / |b1| with a
- *      correctly rounded square root and an IEEE division, the device library's atan2f / acosf.  No entry more than
- *      1e-5 from the reference on well-conditioned inputs; about 2.5x the time.
- *   2  [diagnostic] the arithmetic of 0 through the simple one-column kernel at every shape (what chains shorter than 100
- *      residues take anyway): the cross-check kernel of the parity tests, like ps_k1_config.variant = 1.  Same bits as 0.
+ * exact_angles (ABI 4; bit field since ABI 5), the angle counterpart of ps_k1_config.exact_sqrt:
+ *   bit 0 -- arithmetic.
+ *     0  the fast arithmetic: triple-product dihedral with one reciprocal square root, polynomial atan2 / acos, cosine
+ *        through v_rsq_f32 -- exact where the reference is exact (+0 diagonal, NaN positions), otherwise within the
+ *        conditioning gates of SURVEY hard part 3 (3.8e-6 of off-diagonal dihedrals more than 1e-5 from the reference
+ *        at unit scale, max 6.5e-5; profiles/r04_k3_error_stats.log);
+ *     1  the reference's order of operations (geometry.py:110-124, :64-66): three cross products, y / |b1| with a
+ *        correctly rounded square root and an IEEE division, the device library's atan2f / acosf.  No entry more than
+ *        1e-5 from the reference on well-conditioned inputs.  Since ABI 5 on the same per-CU sweep kernels as the fast
+ *        arithmetic (the library routines restated instruction for instruction in packed form, bit-identical to the
+ *        library calls of the one-column kernel); DESIGN.md section 4 has both modes' times side by side.
+ *   bit 1 -- [diagnostic] the simple one-column kernel at every shape, in the arithmetic bit 0 selects: the layout-free
+ *        cross-check kernel of the parity tests, like ps_k1_config.variant = 1.  Same bits as without it.
+ *   (So 0 = fast, 1 = faithful, 2 = fast / one-column, 3 = faithful / one-column; anything else: hipErrorInvalidValue.)
+ * The device a launch runs on is the stream's (hipStreamGetDevice); for the NULL stream, the calling thread's current device.
  */
 int ps_pairwise_angles_f32(const float* xyz, float* out,
                            int B, int N, int A,
@@ -210,6 +215,41 @@ int ps_pairwise_angles_f32(const float* xyz, float* out,
                            int row_begin, int row_end,
                            int out_rows, int out_row_origin,
                            int exact_angles, void* stream);
+
+/*
+ * Which K3 / featuriser kernel a launch with these arguments takes -- pure host queries (ABI 5): nothing is launched,
+ * no device memory is touched and NO HIP call is made.  They run the launchers' OWN dispatchers in a record-only mode
+ * (same predicates, same grid and LDS arithmetic; K1 has the same arrangement: ps_k1_plan_f32), so the answer cannot
+ * drift from what ps_pairwise_angles_f32 / ps_inter_residue_geometry_f32 do.  `out_misalign`: address of `out` modulo
+ * 16 (a multiple of 4; 0 for anything torch.empty returns); `float_misalign` / `mask_misalign`: the OR of the six fp32 /
+ * three mask plane addresses modulo 128; `cu_count`: compute units of the device (<= 0: 256, an MI355X).  Argument errors
+ * are the launchers' (hipErrorInvalidValue).  No reference counterpart: they exist so that benchmarks and tests can name
+ * the kernel that ran and assert that every arm of the dispatchers is reached by a shape that is held to the oracle.
+ */
+typedef struct ps_k3_plan {
+    int struct_size;            /* in: sizeof(ps_k3_plan) */
+    int n_launches;             /* 0 (empty input) or 1 */
+    char family[32];            /* "sweep" | "small" | "one_column" (K3); "featurise" | "one_column" (featuriser); "empty" */
+    char kernel[96];            /* kernel name with its template arguments, e.g. "k3_sweep<NP=4,SRC=12,NC=4,VEC=1,FAITHFUL=0>" */
+    int columns_per_lane;       /* sweep / featurise: 2 or 4 column residues per lane; small: the padded chain length (16 / 32); else 1 */
+    int vector_stores;          /* 1: the lane's columns are adjacent (8- / 16-byte stores); 0: 64 apart (dword stores, any N) */
+    int skips_dead_groups;      /* 1: dead 64-column groups of a row's last strip are not evaluated */
+    int mask_store_mode;        /* featuriser: 2 strip-local 16-byte stores, 1 flat 16-byte stores, 0 bytes (one-column) */
+    int write_through;          /* featuriser: sc1 stores */
+    int faithful;               /* bit 0 of exact_angles */
+    int rows_per_task;          /* rows of one pulled task (sweep / featurise); rows per workgroup otherwise */
+    int workgroups_per_cu;      /* 1 or 2 for the per-CU kernels (their LDS request pins it), 0: not pinned */
+    int structures_per_segment; /* sweep / featurise: structures staged together (short chains), else 0 */
+    unsigned n_workgroups;
+    int threads_per_workgroup;
+    unsigned lds_bytes;         /* static + dynamic LDS per workgroup */
+    unsigned n_tasks;           /* per-CU kernels: length of the task list, and a workgroup's share of it */
+    unsigned tasks_per_workgroup;
+} ps_k3_plan;
+
+int ps_k3_plan_f32(int B, int N, int A, int n_points, const int* src, const int* atom,
+                   int row_begin, int row_end, int out_rows, int out_row_origin,
+                   int out_misalign, int exact_angles, int cu_count, ps_k3_plan* plan);
 
 /*
  * K4 -- replaces StructureBatch.backbone_orientations + backbone_translations
@@ -306,8 +346,9 @@ int ps_diffusion_trajectory_f32(float* xyz, const float* betas, int T, int B, in
  * exact_sqrt: the square root of the three distance planes, as ps_k1_config.exact_sqrt -- 0: hardware v_sqrt_f32
  * (K1's default: the planes are then bit-identical to the slices of a default K1 launch), 1: correctly rounded
  * (bit-identical to K1 with exact_sqrt = 1).
- * exact_angles (ABI 4): omega, theta and phi in the arithmetic ps_pairwise_angles_f32 uses for the same value (0 fast,
- * 1 the reference's order of operations): the three planes equal the corresponding K3 launches bit for bit in both modes.
+ * exact_angles (ABI 4; bit field since ABI 5): omega, theta and phi in the arithmetic ps_pairwise_angles_f32 uses for the
+ * same value (bit 0: 0 fast, 1 the reference's order of operations; bit 1: the one-column kernel at every shape): the three
+ * planes equal the corresponding K3 launches bit for bit in every mode.
  * Placement of the nine planes: any 4-byte (fp32) / 1-byte (mask) boundary, each plane its own; results do not depend on
  * it.  Fastest where every plane starts on a 16-byte boundary (vector stores; the three mask planes then share one 16-byte
  * grid) -- protstruc_amd.ops pads the plane stride accordingly.
@@ -317,6 +358,10 @@ int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask,
                                   float* omega, float* theta, float* phi,
                                   uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask,
                                   int B, int N, int A, int exact_sqrt, int exact_angles, void* stream);
+
+/* The featuriser's twin of ps_k3_plan_f32 (ABI 5; see there). */
+int ps_featuriser_plan_f32(int B, int N, int A, int float_misalign, int mask_misalign,
+                           int exact_sqrt, int exact_angles, int cu_count, ps_k3_plan* plan);
 
 /*
  * Rigid-body ops.  ps_rigid_f32 replaces StructureBatch.translate,

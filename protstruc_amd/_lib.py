@@ -10,7 +10,7 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PROTSTRUC_AMD_LIB selects another build of the same sources (tools/ use the -DPS_EXPERIMENTS one)
 LIB_PATH = os.environ.get("PROTSTRUC_AMD_LIB") or os.path.join(_HERE, "lib", "libprotstruc_hip.so")
-EXPECTED_ABI = 4  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
+EXPECTED_ABI = 5  # PS_ABI_VERSION of include/protstruc_hip.h; bumped together with any signature change
 
 
 class K1Config(ctypes.Structure):
@@ -25,6 +25,17 @@ class K1Plan(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_int), ("n_launches", ctypes.c_int), ("family", ctypes.c_char * 48),
                 ("kernel", ctypes.c_char * 96), ("n_workgroups", ctypes.c_uint), ("lds_bytes", ctypes.c_uint),
                 ("threads_per_workgroup", ctypes.c_int), ("n_workgroups_2", ctypes.c_uint), ("lds_bytes_2", ctypes.c_uint)]
+
+
+class K3Plan(ctypes.Structure):
+    """``ps_k3_plan`` of include/protstruc_hip.h, field for field."""
+    _fields_ = [("struct_size", ctypes.c_int), ("n_launches", ctypes.c_int), ("family", ctypes.c_char * 32),
+                ("kernel", ctypes.c_char * 96)] + \
+               [(name, ctypes.c_int) for name in ("columns_per_lane", "vector_stores", "skips_dead_groups", "mask_store_mode",
+                                                  "write_through", "faithful", "rows_per_task", "workgroups_per_cu",
+                                                  "structures_per_segment")] + \
+               [("n_workgroups", ctypes.c_uint), ("threads_per_workgroup", ctypes.c_int), ("lds_bytes", ctypes.c_uint),
+                ("n_tasks", ctypes.c_uint), ("tasks_per_workgroup", ctypes.c_uint)]
 
 
 _c_f32p = ctypes.c_void_p
@@ -47,6 +58,9 @@ SIGNATURES = {
                                            _c_int, _c_stream]),
     "ps_pairwise_angles_f32": (_c_int, [_c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int),
                                         ctypes.POINTER(_c_int), _c_int, _c_int, _c_int, _c_int, _c_int, _c_stream]),
+    "ps_k3_plan_f32": (_c_int, [_c_int, _c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)] + [_c_int] * 7 +
+                       [ctypes.POINTER(K3Plan)]),
+    "ps_featuriser_plan_f32": (_c_int, [_c_int] * 8 + [ctypes.POINTER(K3Plan)]),
     "ps_frames_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                                _c_stream]),
     "ps_pointwise_f32": (_c_int, [_c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_longlong, _c_stream]),
@@ -215,6 +229,38 @@ def k1_plan(B, N, A, row_begin=0, row_end=None, *, compact=False, dist_misalign=
             "n_workgroups": plan.n_workgroups, "lds_bytes": plan.lds_bytes,
             "threads_per_workgroup": plan.threads_per_workgroup,
             **({"n_workgroups_2": plan.n_workgroups_2, "lds_bytes_2": plan.lds_bytes_2} if plan.n_launches > 1 else {})}
+
+
+def _k3_plan_dict(plan):
+    d = {name: getattr(plan, name) for name, _ in K3Plan._fields_ if name not in ("struct_size", "family", "kernel")}
+    d["family"], d["kernel"] = plan.family.decode(), plan.kernel.decode()
+    return d
+
+
+def k3_plan(B, N, A, slots_i, slots_j, n_points, row_begin=0, row_end=None, *, compact=False, out_misalign=0, exact_angles=0,
+            cu_count=0):
+    """Which kernel ``ps_pairwise_angles_f32`` takes for this launch: a dict with ``family`` ("sweep", "small",
+    "one_column", "empty"), ``kernel`` (name with template arguments), the layout (``columns_per_lane``, ``vector_stores``,
+    ``skips_dead_groups``, ``faithful``), ``rows_per_task``, ``workgroups_per_cu``, grid, workgroup size and LDS bytes.
+    Pure host query (``ps_k3_plan_f32``): the library runs its own dispatcher in record-only mode; no GPU needed.
+    ``cu_count`` <= 0 means 256 (MI355X)."""
+    row_end = N if row_end is None else row_end
+    out_rows, origin = (row_end - row_begin, row_begin) if compact else (N, 0)
+    slots = [int(v) for v in slots_i] + [int(v) for v in slots_j]
+    src = [0] * len(slots_i) + [1] * len(slots_j)
+    arr = ctypes.c_int * n_points
+    plan = K3Plan(struct_size=ctypes.sizeof(K3Plan))
+    check(load().ps_k3_plan_f32(B, N, A, n_points, arr(*src[:n_points]), arr(*slots[:n_points]), row_begin, row_end, out_rows,
+                                origin, out_misalign, int(exact_angles), cu_count, ctypes.byref(plan)), "ps_k3_plan_f32")
+    return _k3_plan_dict(plan)
+
+
+def featuriser_plan(B, N, A=15, *, float_misalign=0, mask_misalign=0, exact_sqrt=0, exact_angles=0, cu_count=0):
+    """Which kernel ``ps_inter_residue_geometry_f32`` takes (``ps_featuriser_plan_f32``; see ``k3_plan``)."""
+    plan = K3Plan(struct_size=ctypes.sizeof(K3Plan))
+    check(load().ps_featuriser_plan_f32(B, N, A, float_misalign, mask_misalign, int(exact_sqrt), int(exact_angles), cu_count,
+                                        ctypes.byref(plan)), "ps_featuriser_plan_f32")
+    return _k3_plan_dict(plan)
 
 
 _k1_refs = {}      # device index -> (struct, ctypes.byref(struct)) of the device's current settings

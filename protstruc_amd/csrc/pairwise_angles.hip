@@ -17,10 +17,13 @@
 // arithmetic (triple-product dihedral, polynomial atan2 / acos: ps_common.hpp)
 // is where the 1e-5 parity tolerance is spent.
 #include "ps_common.hpp"
+#include "../../include/protstruc_hip.h"
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <initializer_list>
 #include <type_traits>
 
@@ -34,11 +37,24 @@ typedef float k3_f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t k3_u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t k3_u32x2 __attribute__((ext_vector_type(2)));
 
-// CUs of the device the calling thread has current (cached per ordinal; a constant of the device, not library state)
-inline int k3_cu_count() {
-    static int cached[64] = {0};
+// The device a launch on `stream` runs on: the stream's own device; the calling thread's current device for the null stream
+// (a C-ABI caller may launch on a stream of device 1 while device 0 is current: grid size and the LDS attribute are that
+// device's business, not the current one's)
+inline int k3_device_of(hipStream_t stream) {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (stream) {
+        hipDevice_t d;
+        if (hipStreamGetDevice(stream, &d) == hipSuccess) return (int)d;
+    }
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+// CUs of that device (cached per ordinal; a constant of the device, not library state)
+inline int k3_cu_count(hipStream_t stream) {
+    static int cached[64] = {0};
+    const int dev = k3_device_of(stream);
+    if (dev < 0 || dev >= 64) return 256;
     int n = __atomic_load_n(&cached[dev], __ATOMIC_RELAXED);
     if (n <= 0) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -48,21 +64,33 @@ inline int k3_cu_count() {
 }
 
 // More than 64 KB of dynamic LDS has to be allowed once per kernel AND per device (function attributes belong to the module
-// a device loaded).  `done` is the kernel instantiation's own table; idempotent, so a race between two threads is harmless.
+// a device loaded; hipFuncSetAttribute acts on the CURRENT device, so the stream's device is made current around it when it
+// is another one).  `done` is the kernel instantiation's own table; idempotent, so a race between two threads is harmless.
 template <typename K>
-inline int k3_allow_big_lds(K kernel, unsigned long long (&done)[1]) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+inline int k3_allow_big_lds(K kernel, unsigned long long (&done)[1], hipStream_t stream) {
+    const int dev = k3_device_of(stream);
+    if (dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
     const unsigned long long bit = 1ull << dev;
     if (__atomic_load_n(&done[0], __ATOMIC_ACQUIRE) & bit) return 0;
+    int cur = dev;
+    (void)hipGetDevice(&cur);
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return (int)hipErrorInvalidDevice;
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                              (int)(160 * 1024 - 256));
+    if (cur != dev) (void)hipSetDevice(cur);
     if (e != hipSuccess) return (int)e;
     __atomic_fetch_or(&done[0], bit, __ATOMIC_RELEASE);
     return 0;
 }
 
 constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-thread workgroups (two waves per SIMD, 256 VGPRs each)
+// the faithful sweeps take four columns per lane for every split (at most 247 of the 256 VGPRs of their 512-thread workgroups,
+// nothing spilled: tools/kernel_resources.sh; same-box A/B at config 3 against two columns at 1024 threads: 80 / 66 / 43 us against
+// 83 / 74 / 48, profiles/r05_k3_modes_first.log)
+constexpr bool K3_FAITHFUL_NC4(int, int) { return true; }
+// threads of a full-width sweep workgroup: four waves per SIMD with 128 VGPRs each -- two with 256 for the faithful chains at
+// four columns per lane (the library-order chains keep ~2x the values live)
+constexpr int k3_sweep_threads(int NC, bool FAITHFUL) { return FAITHFUL && NC == 4 ? 512 : 1024; }
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
 constexpr size_t K3_LDS_TWO_PER_CU = 80 * 1024 - 256;   // exactly two such workgroups fit a CU (three would need 240 KB)
@@ -142,7 +170,7 @@ __global__ __launch_bounds__(256) void k3_pairwise_angles(const float* __restric
 // or 64 columns x G = 64 / Npad rows at a time; the row-side points are per-lane vector loads (the Npad lanes of a row group
 // share an address), four rows per trip (two packed pairs, their chains interleaved), and a store instruction writes G
 // consecutive rows of the structure.  Same arithmetic per pair as the one-column kernel: same bits.
-template <int NP, int SRC>
+template <int NP, int SRC, bool FAITHFUL = false>
 __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, float* __restrict__ out, int B, int N, int A,
                                                 AtomSel sel, int row_begin, int row_end, int out_rows, int out_row_origin,
                                                 int lg_npad) {
@@ -169,8 +197,12 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
                 P[k][h] = ((SRC >> k) & 1) ? mk3v(pj[k], pj[k]) : mk3v(load3(sa + sel.atom[k] * 3), load3(sb2 + sel.atom[k] * 3));
         }
         f32x2 v[2];
-        if constexpr (NP == 4)
+        if constexpr (NP == 4 && FAITHFUL)
+            dihedral4v_ref_n<2>(P[0], P[1], P[2], P[3], v);
+        else if constexpr (NP == 4)
             dihedral4v_k3_n<2>(P[0], P[1], P[2], P[3], v);
+        else if constexpr (FAITHFUL)
+            angle3v_ref_n<2>(P[0], P[1], P[2], v);
         else
             angle3v_n<2>(P[0], P[1], P[2], v);
 #pragma unroll
@@ -213,8 +245,12 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                        \
                     for (int cc = 0; cc < L; ++cc) P[k][cc] = ((SRC >> k) & 1) ? mk3v(pj[cc][k], pj[cc][k]) : cur[k];    \
                 f32x2 v[L];                                                                                              \
-                if constexpr (NP == 4)                                                                                   \
+                if constexpr (NP == 4 && FAITHFUL)                                                                       \
+                    dihedral4v_ref_n<L>(P[0], P[1], P[2], P[3], v);                                                      \
+                else if constexpr (NP == 4)                                                                              \
                     dihedral4v_k3_n<L>(P[0], P[1], P[2], P[3], v);                                                       \
+                else if constexpr (FAITHFUL)                                                                             \
+                    angle3v_ref_n<L>(P[0], P[1], P[2], v);                                                               \
                 else                                                                                                     \
                     angle3v_n<L>(P[0], P[1], P[2], v);                                                                   \
 _Pragma("unroll")                                                                                                        \
@@ -248,9 +284,9 @@ _Pragma("unroll")                                                               
 _Pragma("unroll")                                                                                                        \
                     for (int k = 0; k < NP; ++k) p[k] = ((SRC >> k) & 1) ? pj[cc][k] : mk3(cur[k].x.x, cur[k].y.x, cur[k].z.x); \
                     if constexpr (NP == 4)                                                                               \
-                        v[cc] = dihedral4_k3(p[0], p[1], p[2], p[3]);                                                    \
+                        v[cc] = FAITHFUL ? dihedral4_ref(p[0], p[1], p[2], p[3]) : dihedral4_k3(p[0], p[1], p[2], p[3]); \
                     else                                                                                                 \
-                        v[cc] = angle3(p[0], p[1], p[2]);                                                                \
+                        v[cc] = FAITHFUL ? angle3_ref(p[0], p[1], p[2]) : angle3(p[0], p[1], p[2]);                      \
                 }                                                                                                        \
                 if constexpr (!VEC) {                                                                                    \
                     const int so = i * row_bytes;                                                                        \
@@ -266,8 +302,8 @@ _Pragma("unroll")                                                               
                 }                                                                                                        \
             }                                                                                                            \
     }
-template <int NP, int SRC, int NC, bool VEC>
-__global__ __launch_bounds__(1024) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
+template <int NP, int SRC, int NC, bool VEC, bool FAITHFUL = false>
+__global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                  AtomSel sel, int row_begin, int row_end, int out_rows,
                                                  int out_row_origin, int CH, int n_strips, int n_chunks,
                                                  unsigned n_tasks, unsigned tasks_per_wg) {
@@ -477,8 +513,8 @@ __global__ __launch_bounds__(256) void k3_inter_residue_geometry(
 //     the bytes outside whole groups written as bytes.
 //   * WT: write-through stores (sc1) where every store covers whole 128-byte lines and strips are whole (N % 128 == 0);
 //     write-back otherwise, so that lines shared by two stores merge in L2 instead of going out as two partial writes.
-template <bool EXACT, int NC, bool VEC, bool M16, bool WT>
-__global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
+template <bool EXACT, int NC, bool VEC, bool M16, bool WT, bool FAITHFUL = false>
+__global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featurise(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
@@ -762,11 +798,14 @@ __global__ __launch_bounds__(NC == 4 ? 512 : 1024) void k3_featurise(
 #pragma unroll
                     for (int cc = 0; cc < L; ++cc) v[cc] = dist3v_t<EXACT>(nv, mk3v(o_j[cc], o_j[cc]));
                     emit(r_dno, v);
-                    angle3v_n<L>(CAV, CBV, CBJ, v);
+                    if constexpr (FAITHFUL) angle3v_ref_n<L>(CAV, CBV, CBJ, v);
+                    else angle3v_n<L>(CAV, CBV, CBJ, v);
                     emit(r_ph, v);
-                    dihedral4v_k3_n<L>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
+                    if constexpr (FAITHFUL) dihedral4v_ref_n<L>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
+                    else dihedral4v_k3_n<L>(CAV, CBV, CAJ, CBJ, v);
                     emit(r_om, v);
-                    dihedral4v_k3_n<L>(NV, CAV, CBV, CBJ, v);
+                    if constexpr (FAITHFUL) dihedral4v_ref_n<L>(NV, CAV, CBV, CBJ, v);
+                    else dihedral4v_k3_n<L>(NV, CAV, CBV, CBJ, v);
                     emit(r_th, v);
                 }
                 };
@@ -796,19 +835,54 @@ inline int k3_rows_per_task(int rows, int min_rows) {
     return std::min(8, std::max(min_rows, ch));
 }
 
-template <int NP, int SRC, int NC, bool VEC>
+// ---- launch context: the dispatchers either launch or only RECORD what they would launch (ps_k3_plan_f32, ----
+// ps_featuriser_plan_f32).  Every K3 / featuriser launch goes through k3_go, so the plan a caller reads is by construction
+// the dispatch a launch takes: same predicates, same grid, same LDS size (K1 has the same arrangement: k1_go).
+struct K3Go {
+    hipStream_t s;
+    ps_k3_plan* plan;   // non-null: record only, launch nothing, make no HIP call
+    int cus;            // compute units of the device the launch is for
+};
+
+struct K3Shape {        // what the plan reports besides the kernel's name and launch geometry
+    int nc = 1, vec = 0, skips = 0, mask_mode = 0, wt = 0, faithful = 0, rows_per_task = 0, wgs_per_cu = 0, structs_per_segment = 0;
+    unsigned n_tasks = 0, tasks_per_wg = 0;
+};
+
+template <typename... KArgs, typename... Args>
+inline int k3_go(const K3Go& go, const char* family, const char* name, const K3Shape& sh, void (*kernel)(KArgs...),
+                 unsigned long long (*prepared)[1], dim3 grid, dim3 block, size_t dyn, unsigned static_lds, Args&&... args) {
+    if (!go.plan) {
+        if (prepared)
+            if (const int e = k3_allow_big_lds(kernel, *prepared, go.s)) return e;
+        return ps_launch(kernel, grid, block, dyn, go.s, static_cast<Args&&>(args)...);
+    }
+    ps_k3_plan& pl = *go.plan;
+    snprintf(pl.family, sizeof pl.family, "%s", family);
+    snprintf(pl.kernel, sizeof pl.kernel, "%s", name);
+    pl.n_launches = 1;
+    pl.columns_per_lane = sh.nc; pl.vector_stores = sh.vec; pl.skips_dead_groups = sh.skips; pl.mask_store_mode = sh.mask_mode;
+    pl.write_through = sh.wt; pl.faithful = sh.faithful; pl.rows_per_task = sh.rows_per_task; pl.workgroups_per_cu = sh.wgs_per_cu;
+    pl.structures_per_segment = sh.structs_per_segment;
+    pl.n_workgroups = grid.x; pl.threads_per_workgroup = (int)block.x; pl.lds_bytes = (unsigned)dyn + static_lds;
+    pl.n_tasks = sh.n_tasks; pl.tasks_per_workgroup = sh.tasks_per_wg;
+    return 0;
+}
+
+template <int NP, int SRC, int NC, bool VEC, bool FAITHFUL>
 int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
-                 int out_rows, int out_row_origin, hipStream_t s) {
+                 int out_rows, int out_row_origin, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
-    const int rows = row_end - row_begin, cus = k3_cu_count();
+    constexpr int THREADS = k3_sweep_threads(NC, FAITHFUL);
+    const int rows = row_end - row_begin, cus = go.cus;
     const int n_strips = (N + 64 * NC - 1) / (64 * NC);
     const int CH = k3_rows_per_task(rows, 2);
     const int n_chunks = (rows + CH - 1) / CH;
     const unsigned long long n_tasks = (unsigned long long)n_strips * n_chunks * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const size_t need = (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8;   // one segment's rows, pair-interleaved
-    // Every CU one 1024-thread workgroup -- or, when a workgroup would walk four or more (structure, strip) segments (chains
-    // of ~128 residues in large batches), TWO 512-thread workgroups: a segment's set-up (two barriers, the global-load latency
+    // Every CU one full-width workgroup -- or, when a workgroup would walk four or more (structure, strip) segments (chains
+    // of ~128 residues in large batches), TWO of half the width: a segment's set-up (two barriers, the global-load latency
     // of its rows and column points) idles all of a workgroup's waves for ~1.8 us, and a second workgroup on the CU computes
     // meanwhile.  Their LDS requests admit exactly two per CU.  Short lists: at least 4 tasks per workgroup.
     const unsigned long long segs = (unsigned long long)n_strips * B;
@@ -818,9 +892,13 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
     const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
     static unsigned long long prepared[1] = {0};   // bit d: device d allows this kernel its dynamic LDS
-    if (const int e = k3_allow_big_lds(k3_sweep<NP, SRC, NC, VEC>, prepared)) return e;
-    return ps_launch(k3_sweep<NP, SRC, NC, VEC>, dim3(grid), dim3(two ? 512 : 1024), dyn, s, xyz, out, N, A, sel, row_begin, row_end,
-                     out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
+    char name[96];
+    snprintf(name, sizeof name, "k3_sweep<NP=%d,SRC=%d,NC=%d,VEC=%d,FAITHFUL=%d>", NP, SRC, NC, (int)VEC, (int)FAITHFUL);
+    K3Shape sh;
+    sh.nc = NC; sh.vec = VEC; sh.skips = !VEC && !(NP == 4 && SRC == 12 && NC == 4 && !FAITHFUL); sh.faithful = FAITHFUL; sh.rows_per_task = CH;
+    sh.wgs_per_cu = two ? 2 : 1; sh.structs_per_segment = 1; sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
+    return k3_go(go, "sweep", name, sh, k3_sweep<NP, SRC, NC, VEC, FAITHFUL>, &prepared, dim3(grid), dim3(THREADS >> (two ? 1 : 0)), dyn, 4u,
+                 xyz, out, N, A, sel, row_begin, row_end, out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
 }
 
 // One-column kernels: a workgroup as wide as the chain needs (whole waves, at most 256 lanes) -- with 256 lanes for a
@@ -837,71 +915,123 @@ constexpr int K3_SWEEP_MIN_N = 100;
 constexpr int K3_FEATURISE_MIN_N = 64;
 constexpr int K3_SMALL_MAX_N = 32;    // k3_small: one wave per structure (33..64 measured: no better than the one-column kernel)
 
-template <int NP, int SRC>
+template <int NP, int SRC, bool FAITHFUL>
+int launch_one_column(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
+                      int out_rows, int out_row_origin, const K3Go& go) {
+    const int rows = row_end - row_begin, thr1 = k3_one_column_threads(N), IR = 16;
+    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (rows + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    char name[96];
+    snprintf(name, sizeof name, "k3_pairwise_angles<NP=%d,SRC=%d,FAITHFUL=%d>", NP, SRC, (int)FAITHFUL);
+    K3Shape sh;
+    sh.faithful = FAITHFUL; sh.rows_per_task = IR;
+    return k3_go(go, "one_column", name, sh, k3_pairwise_angles<NP, SRC, FAITHFUL>, nullptr, dim3((unsigned)n_wg), dim3(thr1), 0, 0u, xyz, out,
+                 N, A, sel, row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+}
+
+// mode = exact_angles of the C ABI: bit 0 = the reference's order of operations (FAITHFUL), bit 1 = the one-column kernel
+// whatever the shape (diagnostic: the layout-free twin the sweep kernels are held to, bit for bit, in either arithmetic)
+template <int NP, int SRC, bool FAITHFUL>
 int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end,
-           int out_rows, int out_row_origin, int mode, hipStream_t s) {   // mode = exact_angles of the C ABI
-    const bool faithful = mode == 1, simple = mode == 2;
+           int out_rows, int out_row_origin, bool simple, unsigned out_misalign, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin;
-    const int thr1 = k3_one_column_threads(N);
-    if (faithful) {
-        const int IR = 16;
-        const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (rows + IR - 1) / IR;
-        const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
-        if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        return ps_launch(k3_pairwise_angles<NP, SRC, true>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
-                         row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
-    }
     if (!simple && N <= K3_SMALL_MAX_N) {   // short chains: lanes = (row group, column), one wave per structure
         const unsigned long long n_wg = ((unsigned long long)B + 3) / 4;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-        return ps_launch(k3_small<NP, SRC>, dim3((unsigned)n_wg), dim3(256), 0, s, xyz, out, B, N, A, sel, row_begin, row_end,
-                         out_rows, out_row_origin, N <= 16 ? 4 : N <= 32 ? 5 : 6);
+        char name[96];
+        snprintf(name, sizeof name, "k3_small<NP=%d,SRC=%d,FAITHFUL=%d>", NP, SRC, (int)FAITHFUL);
+        K3Shape sh;
+        sh.faithful = FAITHFUL; sh.rows_per_task = 4 * (64 >> (N <= 16 ? 4 : 5)); sh.nc = N <= 16 ? 16 : 32;
+        return k3_go(go, "small", name, sh, k3_small<NP, SRC, FAITHFUL>, nullptr, dim3((unsigned)n_wg), dim3(256), 0, 0u, xyz, out, B, N, A, sel,
+                     row_begin, row_end, out_rows, out_row_origin, N <= 16 ? 4 : N <= 32 ? 5 : 6);
     }
-    const uintptr_t al = reinterpret_cast<uintptr_t>(out);
-    // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS
-    const bool fits = !simple && N >= K3_SWEEP_MIN_N && (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX;
+    // NC columns per lane need N % NC == 0 and 4 * NC-byte aligned rows; the segment's rows have to fit the LDS, and its
+    // output has to be addressable by the kernel's 32-bit byte offsets (a row-sharded call on a very long chain)
+    const bool fits = !simple && N >= K3_SWEEP_MIN_N && (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX &&
+                      (unsigned long long)rows * (unsigned long long)N * 4ull < (1ull << 31);
     // four columns per lane only where the instantiation keeps its registers (three or two column-side points of a
-    // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers)
-    constexpr bool NC4 = NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 12 || SRC == 15;
-    const bool ok4 = NC4 && fits && N % 4 == 0 && (al & 15u) == 0, ok2 = fits && N % 2 == 0 && (al & 7u) == 0;
+    // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers; the faithful
+    // kernels' 512-thread workgroups have 256 and take four columns for every split)
+    constexpr bool NC4 = FAITHFUL ? K3_FAITHFUL_NC4(NP, SRC)
+                                  : (NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 12 || SRC == 15);
+#ifdef PS_K3_AB
+    static const int force_nc = getenv("PS_K3_NC") ? atoi(getenv("PS_K3_NC")) : 0;
+    const bool allow4 = force_nc != 2;
+#else
+    const bool allow4 = true;
+#endif
+    const bool ok4 = NC4 && allow4 && fits && N % 4 == 0 && (out_misalign & 15u) == 0, ok2 = fits && N % 2 == 0 && (out_misalign & 7u) == 0;
     // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
     const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
     // The 64-apart layout skips the dead column groups of a row's last strip: it computes ceil(N / 64) groups per row pair
     // where the vector layouts compute whole strips -- taken also for even N where that saves more than its dword stores cost
     const long long gn = (N + 63) / 64, gv = (NC4 && ok4 && (!ok2 || w4 <= w2) ? w4 : w2) / 64;
-    constexpr bool SKIPS = !(NP == 4 && SRC == 12);   // (the (2,2) dihedral's four-column instantiation evaluates every group: registers)
+    constexpr bool SKIPS = FAITHFUL || !(NP == 4 && SRC == 12);   // (the fast (2,2) dihedral's four-column instantiation evaluates every group: registers)
     if ((ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100)) {
         if constexpr (NC4) {
             if (ok4 && (!ok2 || w4 <= w2))
-                return launch_sweep<NP, SRC, 4, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+                return launch_sweep<NP, SRC, 4, true, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
         }
-        return launch_sweep<NP, SRC, 2, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+        return launch_sweep<NP, SRC, 2, true, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (fits) {   // odd N, a misaligned output, or fewer groups: the same sweep with the lane's columns 64 apart and dword stores
         if constexpr (NC4) {   // four columns from three groups on where dead groups are skipped; else by the lanes a strip wastes
-            if (SKIPS ? gn > 2 : w4 <= w2)
-                return launch_sweep<NP, SRC, 4, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+            if (allow4 && (SKIPS ? gn > 2 : w4 <= w2))
+                return launch_sweep<NP, SRC, 4, false, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
         }
-        return launch_sweep<NP, SRC, 2, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, s);
+        return launch_sweep<NP, SRC, 2, false, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
     }
-    const int IR = 16;
-    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (rows + IR - 1) / IR;
-    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
-    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    return ps_launch(k3_pairwise_angles<NP, SRC, false>, dim3((unsigned)n_wg), dim3(thr1), 0, s, xyz, out, N, A, sel,
-                     row_begin, row_end, out_rows, out_row_origin, IR, n_tiles, n_chunks);
+    return launch_one_column<NP, SRC, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
 }
 
 template <int NP, int... SRCS>
 int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin,
-             int row_end, int out_rows, int out_row_origin, int mode, hipStream_t s) {
+             int row_end, int out_rows, int out_row_origin, int mode, unsigned out_misalign, const K3Go& go) {
     int rc = (int)hipErrorInvalidValue;
-    (void)((srcmask == SRCS
-                ? (rc = launch<NP, SRCS>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, mode, s), true)
-                : false) ||
-           ...);
+    const bool simple = (mode & 2) != 0;
+    if (mode & 1)
+        (void)((srcmask == SRCS ? (rc = launch<NP, SRCS, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, simple, out_misalign, go), true)
+                                : false) || ...);
+    else
+        (void)((srcmask == SRCS ? (rc = launch<NP, SRCS, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, simple, out_misalign, go), true)
+                                : false) || ...);
     return rc;
+}
+
+// argument checks shared by the launcher and the plan query
+inline int k3_check_args(int B, int N, int A, int n_points, const int* src, const int* atom, int row_begin, int row_end, int out_rows,
+                         int out_row_origin, int exact_angles, AtomSel& sel, int& srcmask) {
+    if (!src || !atom || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
+    if (exact_angles < 0 || exact_angles > 3) return (int)hipErrorInvalidValue;
+    if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
+    if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
+    if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
+    sel = AtomSel{};
+    srcmask = 0;
+    for (int k = 0; k < n_points; ++k) {
+        if (atom[k] < 0 || atom[k] >= A || (src[k] != 0 && src[k] != 1)) return (int)hipErrorInvalidValue;
+        sel.atom[k] = atom[k];
+        srcmask |= src[k] << k;
+    }
+    return 0;
+}
+
+inline int k3_run(const float* xyz, float* out, int B, int N, int A, int n_points, const AtomSel& sel, int srcmask, int row_begin,
+                  int row_end, int out_rows, int out_row_origin, int exact_angles, unsigned out_misalign, const K3Go& go) {
+    if (n_points == 4)
+        return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
+                                                                                 out_row_origin, exact_angles, out_misalign, go);
+    return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, exact_angles,
+                                               out_misalign, go);
+}
+
+inline void k3_plan_reset(ps_k3_plan* plan) {
+    const int sz = plan->struct_size;
+    memset(plan, 0, sizeof *plan);
+    plan->struct_size = sz;
+    snprintf(plan->family, sizeof plan->family, "empty");
 }
 
 }  // namespace
@@ -909,26 +1039,146 @@ int dispatch(int srcmask, const float* xyz, float* out, int B, int N, int A, con
 extern "C" int ps_pairwise_angles_f32(const float* xyz, float* out, int B, int N, int A, int n_points, const int* src,
                                       const int* atom, int row_begin, int row_end, int out_rows, int out_row_origin,
                                       int exact_angles, void* stream) {
-    if (!xyz || !out || !src || !atom || B < 0 || N < 0 || A <= 0) return (int)hipErrorInvalidValue;
-    if (exact_angles < 0 || exact_angles > 2) return (int)hipErrorInvalidValue;
-    if (n_points != 3 && n_points != 4) return (int)hipErrorInvalidValue;
-    if (row_begin < 0 || row_end > N || row_begin > row_end) return (int)hipErrorInvalidValue;
-    if (out_row_origin > row_begin || row_end - out_row_origin > out_rows) return (int)hipErrorInvalidValue;
-    AtomSel sel{};
+    if (!xyz || !out) return (int)hipErrorInvalidValue;
+    AtomSel sel;
     int srcmask = 0;
-    for (int k = 0; k < n_points; ++k) {
-        if (atom[k] < 0 || atom[k] >= A || (src[k] != 0 && src[k] != 1)) return (int)hipErrorInvalidValue;
-        sel.atom[k] = atom[k];
-        srcmask |= src[k] << k;
-    }
+    if (const int e = k3_check_args(B, N, A, n_points, src, atom, row_begin, row_end, out_rows, out_row_origin, exact_angles, sel, srcmask))
+        return e;
     if (B == 0 || N == 0 || row_begin == row_end) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (n_points == 4)
-        return dispatch<4, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15>(
-            srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, exact_angles, s);
-    return dispatch<3, 0, 1, 2, 3, 4, 5, 6, 7>(srcmask, xyz, out, B, N, A, sel, row_begin, row_end, out_rows,
-                                               out_row_origin, exact_angles, s);
+    const K3Go go{s, nullptr, k3_cu_count(s)};
+    return k3_run(xyz, out, B, N, A, n_points, sel, srcmask, row_begin, row_end, out_rows, out_row_origin, exact_angles,
+                  (unsigned)(reinterpret_cast<uintptr_t>(out) & 15u), go);
 }
+
+extern "C" int ps_k3_plan_f32(int B, int N, int A, int n_points, const int* src, const int* atom, int row_begin, int row_end,
+                              int out_rows, int out_row_origin, int out_misalign, int exact_angles, int cu_count,
+                              ps_k3_plan* plan) {
+    if (!plan || plan->struct_size != (int)sizeof(ps_k3_plan)) return (int)hipErrorInvalidValue;
+    k3_plan_reset(plan);
+    AtomSel sel;
+    int srcmask = 0;
+    if (const int e = k3_check_args(B, N, A, n_points, src, atom, row_begin, row_end, out_rows, out_row_origin, exact_angles, sel, srcmask))
+        return e;
+    if (out_misalign < 0 || out_misalign > 15 || (out_misalign & 3)) return (int)hipErrorInvalidValue;
+    if (B == 0 || N == 0 || row_begin == row_end) return 0;
+    const K3Go go{nullptr, plan, cu_count > 0 ? cu_count : 256};
+    return k3_run(nullptr, nullptr, B, N, A, n_points, sel, srcmask, row_begin, row_end, out_rows, out_row_origin, exact_angles,
+                  (unsigned)out_misalign, go);
+}
+
+namespace {
+
+// argument checks shared by the featuriser's launcher and its plan query
+inline int k3f_check_args(int B, int N, int A, int exact_sqrt, int exact_angles) {
+    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || exact_angles < 0 || exact_angles > 3)
+        return (int)hipErrorInvalidValue;
+    return 0;
+}
+
+// one featuriser instantiation by its run-time switches (EXACT: the distance planes' square root)
+template <int NC, bool VEC, bool M16, bool WT, bool FAITHFUL, typename... Args>
+inline int k3f_go(const K3Go& go, bool exact_sqrt, const K3Shape& sh, dim3 grid, dim3 block, size_t dyn, Args&&... args) {
+    static unsigned long long prep[2][1] = {{0}, {0}};
+    char name[96];
+    snprintf(name, sizeof name, "k3_featurise<EXACT=%d,NC=%d,VEC=%d,M16=%d,WT=%d,FAITHFUL=%d>", (int)exact_sqrt, NC, (int)VEC, (int)M16, (int)WT,
+             (int)FAITHFUL);
+    if (exact_sqrt)
+        return k3_go(go, "featurise", name, sh, k3_featurise<true, NC, VEC, M16, WT, FAITHFUL>, &prep[0], grid, block, dyn, 4u, static_cast<Args&&>(args)...);
+    return k3_go(go, "featurise", name, sh, k3_featurise<false, NC, VEC, M16, WT, FAITHFUL>, &prep[1], grid, block, dyn, 4u, static_cast<Args&&>(args)...);
+}
+
+template <bool FAITHFUL>
+int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb, float* d_no, float* omega, float* theta, float* phi,
+            uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask, int B, int N, int A, int exact_sqrt, bool simple, uintptr_t alf,
+            uintptr_t alm, const K3Go& go) {
+    // one structure's rows (points + mask words), its column points, its column masks (bytes or bit sets)
+    const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
+                        std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
+    // the per-CU sweep: any N >= K3_FEATURISE_MIN_N whose rows fit in LDS
+    if (!simple && N >= K3_FEATURISE_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
+        // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
+        // columns per lane by the lanes a strip wastes
+        const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
+        const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
+        // ... or none at all: with the 64-floats-per-store layout the dead column groups of a row's last strip are skipped, so
+        // it computes ceil(N / 64) groups per row pair where the vector layouts compute whole strips (N = 140: 3 against 4,
+        // 342 against 376 us at 2^25 pairs) -- taken where that saves more than the ~15 % its dword stores cost
+        constexpr bool CAN4 = K3_FEATURISE_NC4 && !FAITHFUL;   // (the faithful chains of four columns do not fit 256 VGPRs)
+        const long long gn = (N + 63) / 64, gv = (CAN4 ? std::min(w4, w2) : w2) / 64;
+        const bool prefer_scalar = gn * 115 < gv * 100;
+        int NC = (CAN4 && w4 <= w2) ? 4 : 2;
+        const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
+        // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
+        // 257 / 267; two groups, N = 101: 338 / 310)
+        if (!vec) NC = (CAN4 && gn > 2) ? 4 : 2;
+        const bool m16 = vec && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
+        // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
+        // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
+        const bool wt = m16 && N % 128 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;
+        const int cus = go.cus;
+        const int n_strips = (N + 64 * NC - 1) / (64 * NC);
+        // a task is CH rows x one strip, the strips of a row chunk adjacent tasks: a workgroup's share has to be many tasks
+        // per wave whatever B and N are -- its waves wait for each other at every structure boundary for up to one task.
+        // Four rows with the M16 mask stores (four rows per instruction; rows are whole 64-byte segments there).  TWO
+        // otherwise: where rows are not whole segments, the segment a row's strips share and the one a row's end shares with
+        // the next row's start get their halves from adjacent tasks, i.e. from two waves up to a task apart -- with
+        // four-row tasks (~16 us) longer than a line stays in L2 at this store rate, so that half of them went out as two
+        // partial writes (2.2 % of the write requests at N = 500, none at N = 496: profiles/r04_featuriser_pmc.log);
+        // same-box A/B, trace: N = 500 260 -> 228 us, 511 264 -> 241, 255 238 -> 218.
+        const bool two_wg = (unsigned long long)B >= 4ull * cus;
+        const int CH = m16 ? 4 : 2;
+        const int n_chunks = (N + CH - 1) / CH;
+        const unsigned long long n_tasks = (unsigned long long)n_chunks * n_strips * B;
+        if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+        // One workgroup per CU -- or, when a CU's share is four or more structures (chains of ~128 residues in large
+        // batches), TWO of half the width: staging a structure (two barriers, a round trip to L2 for its rows and column
+        // points) idles all of a workgroup's waves, and the other workgroup computes meanwhile.  Their LDS requests admit
+        // exactly one / two per CU.
+        const bool two = two_wg && need <= K3_LDS_TWO_PER_CU;
+        const int wgs = two ? 2 * cus : cus;
+        const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + wgs - 1) / wgs, 4ull);
+        const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+        const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
+        const unsigned rcpN = (unsigned)((1ull << 32) / (unsigned)N);
+        // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves; so do
+        // the faithful chains of two columns
+        const dim3 block((unsigned)(((NC == 4 || FAITHFUL) ? 512 : 1024) >> (two ? 1 : 0)));
+        K3Shape sh;
+        sh.nc = NC; sh.vec = vec; sh.skips = !vec; sh.mask_mode = m16 ? 2 : 1; sh.wt = wt; sh.faithful = FAITHFUL; sh.rows_per_task = CH;
+        sh.wgs_per_cu = two ? 2 : 1; sh.structs_per_segment = 1; sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
+#define K3F_GO(NC_, VEC_, M16_, WT_)                                                                                              \
+    return k3f_go<NC_, VEC_, M16_, WT_, FAITHFUL>(go, exact_sqrt != 0, sh, dim3(grid), block, dyn, xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, \
+                                                  phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks, (unsigned)n_tasks,  \
+                                                  tasks_per_wg, rcpN)
+        if (wt && NC == 2) K3F_GO(2, true, true, true);
+        if (m16 && NC == 2) K3F_GO(2, true, true, false);
+        if constexpr (CAN4) {
+            if (wt) K3F_GO(4, true, true, true);
+            if (m16) K3F_GO(4, true, true, false);
+            if (NC == 4 && vec) K3F_GO(4, true, false, false);
+            if (NC == 4) K3F_GO(4, false, false, false);
+        }
+        if (vec) K3F_GO(2, true, false, false);
+        K3F_GO(2, false, false, false);
+#undef K3F_GO
+    }
+    const int IR = 16, thr1 = k3_one_column_threads(N);
+    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (N + IR - 1) / IR;
+    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
+    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    char name[96];
+    snprintf(name, sizeof name, "k3_inter_residue_geometry<EXACT=%d,FAITHFUL=%d>", exact_sqrt, (int)FAITHFUL);
+    K3Shape sh;
+    sh.faithful = FAITHFUL; sh.rows_per_task = IR;
+    auto one = [&](auto kernel) {
+        return k3_go(go, "one_column", name, sh, kernel, nullptr, dim3((unsigned)n_wg), dim3(thr1), 0, 0u, xyz, atom_mask, d_ca, d_cb, d_no, omega,
+                     theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
+    };
+    return exact_sqrt ? one(k3_inter_residue_geometry<true, FAITHFUL>) : one(k3_inter_residue_geometry<false, FAITHFUL>);
+}
+
+}  // namespace
 
 extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb,
                                              float* d_no, float* omega, float* theta, float* phi, uint8_t* d_ca_mask,
@@ -936,89 +1186,32 @@ extern "C" int ps_inter_residue_geometry_f32(const float* xyz, const uint8_t* at
                                              int exact_sqrt, int exact_angles, void* stream) {
     if (!xyz || !d_ca || !d_cb || !d_no || !omega || !theta || !phi || !d_ca_mask || !d_cb_mask || !d_no_mask)
         return (int)hipErrorInvalidValue;
-    if (B < 0 || N < 0 || A < 5 || (exact_sqrt != 0 && exact_sqrt != 1) || exact_angles < 0 || exact_angles > 2)
-        return (int)hipErrorInvalidValue;
+    if (const int e = k3f_check_args(B, N, A, exact_sqrt, exact_angles)) return e;
     if (B == 0 || N == 0) return 0;
-    if (exact_angles == 0) {   // the per-CU sweep: any N >= K3_FEATURISE_MIN_N whose rows fit in LDS
-        uintptr_t alf = 0, alm = 0;
-        for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega,
-                              (const void*)theta, (const void*)phi})
-            alf |= reinterpret_cast<uintptr_t>(p);
-        for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask})
-            alm |= reinterpret_cast<uintptr_t>(p);
-        // one structure's rows (points + mask words), its column points, its column masks (bytes or bit sets)
-        const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
-                            std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
-        if (N >= K3_FEATURISE_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
-            // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
-            // columns per lane by the lanes a strip wastes
-            const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
-            const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
-            // ... or none at all: with the 64-floats-per-store layout the dead column groups of a row's last strip are skipped, so
-            // it computes ceil(N / 64) groups per row pair where the vector layouts compute whole strips (N = 140: 3 against 4,
-            // 342 against 376 us at 2^25 pairs) -- taken where that saves more than the ~15 % its dword stores cost
-            const long long gn = (N + 63) / 64, gv = std::min(w4, w2) / 64;
-            const bool prefer_scalar = gn * 115 < gv * 100;
-            int NC = (K3_FEATURISE_NC4 && w4 <= w2) ? 4 : 2;
-            const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
-            // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
-            // 257 / 267; two groups, N = 101: 338 / 310)
-            if (!vec) NC = (K3_FEATURISE_NC4 && gn > 2) ? 4 : 2;
-            const bool m16 = vec && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
-            // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
-            // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
-            const bool wt = m16 && N % 128 == 0 && (alf & 127u) == 0 && (alm & 127u) == 0;
-            const int cus = k3_cu_count();
-            const int n_strips = (N + 64 * NC - 1) / (64 * NC);
-            // a task is CH rows x one strip, the strips of a row chunk adjacent tasks: a workgroup's share has to be many tasks
-            // per wave whatever B and N are -- its waves wait for each other at every structure boundary for up to one task.
-            // Four rows with the M16 mask stores (four rows per instruction; rows are whole 64-byte segments there).  TWO
-            // otherwise: where rows are not whole segments, the segment a row's strips share and the one a row's end shares with
-            // the next row's start get their halves from adjacent tasks, i.e. from two waves up to a task apart -- with
-            // four-row tasks (~16 us) longer than a line stays in L2 at this store rate, so that half of them went out as two
-            // partial writes (2.2 % of the write requests at N = 500, none at N = 496: profiles/r04_featuriser_pmc.log);
-            // same-box A/B, trace: N = 500 260 -> 228 us, 511 264 -> 241, 255 238 -> 218.
-            const bool two_wg = (unsigned long long)B >= 4ull * cus;
-            const int CH = m16 ? 4 : 2;
-            const int n_chunks = (N + CH - 1) / CH;
-            const unsigned long long n_tasks = (unsigned long long)n_chunks * n_strips * B;
-            if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-            // One workgroup per CU -- or, when a CU's share is four or more structures (chains of ~128 residues in large
-            // batches), TWO of half the width: staging a structure (two barriers, a round trip to L2 for its rows and column
-            // points) idles all of a workgroup's waves, and the other workgroup computes meanwhile.  Their LDS requests admit
-            // exactly one / two per CU.
-            const bool two = two_wg && need <= K3_LDS_TWO_PER_CU;
-            const int wgs = two ? 2 * cus : cus;
-            const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + wgs - 1) / wgs, 4ull);
-            const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
-            const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
-            const unsigned rcpN = (unsigned)((1ull << 32) / (unsigned)N);
-            auto go = [&](auto kernel, unsigned long long (&prepared)[1]) -> int {
-                if (const int e = k3_allow_big_lds(kernel, prepared)) return e;
-                // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves
-                return ps_launch(kernel, dim3(grid), dim3((NC == 4 ? 512 : 1024) >> (two ? 1 : 0)), dyn, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask, d_ca,
-                                 d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks,
-                                 (unsigned)n_tasks, tasks_per_wg, rcpN);
-            };
-            static unsigned long long prep[16][1] = {{0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}, {0}};
-            if (wt && NC == 2) return exact_sqrt ? go(k3_featurise<true, 2, true, true, true>, prep[12]) : go(k3_featurise<false, 2, true, true, true>, prep[13]);
-            if (m16 && NC == 2) return exact_sqrt ? go(k3_featurise<true, 2, true, true, false>, prep[14]) : go(k3_featurise<false, 2, true, true, false>, prep[15]);
-            if (wt) return exact_sqrt ? go(k3_featurise<true, 4, true, true, true>, prep[0]) : go(k3_featurise<false, 4, true, true, true>, prep[1]);
-            if (m16) return exact_sqrt ? go(k3_featurise<true, 4, true, true, false>, prep[2]) : go(k3_featurise<false, 4, true, true, false>, prep[3]);
-            if (NC == 4 && vec) return exact_sqrt ? go(k3_featurise<true, 4, true, false, false>, prep[4]) : go(k3_featurise<false, 4, true, false, false>, prep[5]);
-            if (NC == 4) return exact_sqrt ? go(k3_featurise<true, 4, false, false, false>, prep[6]) : go(k3_featurise<false, 4, false, false, false>, prep[7]);
-            if (vec) return exact_sqrt ? go(k3_featurise<true, 2, true, false, false>, prep[8]) : go(k3_featurise<false, 2, true, false, false>, prep[9]);
-            return exact_sqrt ? go(k3_featurise<true, 2, false, false, false>, prep[10]) : go(k3_featurise<false, 2, false, false, false>, prep[11]);
-        }
-    }
-    const int IR = 16, thr1 = k3_one_column_threads(N);
-    const int n_tiles = (N + thr1 - 1) / thr1, n_chunks = (N + IR - 1) / IR;
-    const unsigned long long n_wg = (unsigned long long)n_tiles * n_chunks * B;
-    if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
-    auto go = [&](auto kernel) {
-        return ps_launch(kernel, dim3((unsigned)n_wg), dim3(thr1), 0, reinterpret_cast<hipStream_t>(stream), xyz, atom_mask,
-                         d_ca, d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, IR, n_tiles, n_chunks);
-    };
-    if (exact_angles == 1) return exact_sqrt ? go(k3_inter_residue_geometry<true, true>) : go(k3_inter_residue_geometry<false, true>);
-    return exact_sqrt ? go(k3_inter_residue_geometry<true, false>) : go(k3_inter_residue_geometry<false, false>);
+    uintptr_t alf = 0, alm = 0;
+    for (const void* p : {(const void*)d_ca, (const void*)d_cb, (const void*)d_no, (const void*)omega, (const void*)theta, (const void*)phi})
+        alf |= reinterpret_cast<uintptr_t>(p);
+    for (const void* p : {(const void*)d_ca_mask, (const void*)d_cb_mask, (const void*)d_no_mask}) alm |= reinterpret_cast<uintptr_t>(p);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const K3Go go{s, nullptr, k3_cu_count(s)};
+    const bool simple = (exact_angles & 2) != 0;
+    if (exact_angles & 1)
+        return k3f_run<true>(xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, B, N, A, exact_sqrt, simple, alf & 127u, alm & 127u, go);
+    return k3f_run<false>(xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, B, N, A, exact_sqrt, simple, alf & 127u, alm & 127u, go);
+}
+
+extern "C" int ps_featuriser_plan_f32(int B, int N, int A, int float_misalign, int mask_misalign, int exact_sqrt, int exact_angles,
+                                      int cu_count, ps_k3_plan* plan) {
+    if (!plan || plan->struct_size != (int)sizeof(ps_k3_plan)) return (int)hipErrorInvalidValue;
+    k3_plan_reset(plan);
+    if (const int e = k3f_check_args(B, N, A, exact_sqrt, exact_angles)) return e;
+    if (float_misalign < 0 || float_misalign > 127 || mask_misalign < 0 || mask_misalign > 127) return (int)hipErrorInvalidValue;
+    if (B == 0 || N == 0) return 0;
+    const K3Go go{nullptr, plan, cu_count > 0 ? cu_count : 256};
+    const bool simple = (exact_angles & 2) != 0;
+    if (exact_angles & 1)
+        return k3f_run<true>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, A, exact_sqrt, simple,
+                             (uintptr_t)float_misalign, (uintptr_t)mask_misalign, go);
+    return k3f_run<false>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, A, exact_sqrt, simple,
+                          (uintptr_t)float_misalign, (uintptr_t)mask_misalign, go);
 }

@@ -524,6 +524,172 @@ __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     return acos_ps(dot3(ba, bc) * __builtin_amdgcn_rsqf(q));
 }
 
+// ---- the FAITHFUL forms for NC columns x two rows (round 5): dihedral4_ref / angle3_ref bit for bit, packed ----
+// dihedral4_ref / angle3_ref above call the device library (atan2f, acosf) and the compiler's IEEE division once per
+// element: ~150 unpacked VALU instructions per dihedral.  What follows are the SAME operations, instruction for
+// instruction as hipcc (ROCm 7.2, -O3 -ffp-contract=off) emits them for those calls on gfx950 -- read off the ISA of a
+// one-line kernel per function and off ocml.bc's IR -- with the multiplies, adds and fused multiply-adds of two rows issued
+// as one v_pk_*_f32 and the NC columns' dependent chains interleaved.  An IEEE fma / mul / add gives the same bits whether
+// it issues as v_fma_f32 or as half of v_pk_fma_f32, so the results equal the library's bit for bit; that equality is
+// not assumed but tested: tests/test_gpu_parity.py holds these kernels to the one-column kernel (which calls the
+// library) on every split, length and special value, and tools/microbench/libm_identity.hip sweeps 2^32 argument pairs.
+//
+// a / b, IEEE-correct: the expansion of fdiv (v_div_scale_f32 x2, v_rcp_f32, the Newton / residual chain, v_div_fmas_f32,
+// v_div_fixup_f32); the chain's six operations packed.
+template <int NC>
+__device__ __forceinline__ void div_ieee_vn(const f32x2 (&a)[NC], const f32x2 (&b)[NC], f32x2 (&o)[NC]) {
+    f32x2 ds[NC], ns[NC], r[NC], q[NC], t[NC];
+    bool fx[NC], fy[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        bool unused;
+        ds[c] = f32x2{__builtin_amdgcn_div_scalef(a[c].x, b[c].x, false, &unused), __builtin_amdgcn_div_scalef(a[c].y, b[c].y, false, &unused)};
+        ns[c] = f32x2{__builtin_amdgcn_div_scalef(a[c].x, b[c].x, true, &fx[c]), __builtin_amdgcn_div_scalef(a[c].y, b[c].y, true, &fy[c])};
+        r[c] = f32x2{__builtin_amdgcn_rcpf(ds[c].x), __builtin_amdgcn_rcpf(ds[c].y)};
+    }
+    const f32x2 one = {1.0f, 1.0f};
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = __builtin_elementwise_fma(-ds[c], r[c], one);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) r[c] = __builtin_elementwise_fma(t[c], r[c], r[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) q[c] = ns[c] * r[c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = __builtin_elementwise_fma(-ds[c], q[c], ns[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) q[c] = __builtin_elementwise_fma(t[c], r[c], q[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = __builtin_elementwise_fma(-ds[c], q[c], ns[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+        o[c] = f32x2{__builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(t[c].x, r[c].x, q[c].x, fx[c]), b[c].x, a[c].x),
+                     __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(t[c].y, r[c].y, q[c].y, fy[c]), b[c].y, a[c].y)};
+}
+
+// atan2f of the device library (__ocml_atan2_f32 with denormals on, finite-only off): v / u of min / max by the 2.5-ulp
+// division the library asks for (frexp mantissas, v_rcp_f32, v_ldexp_f32), the degree-8 odd polynomial __ocmlpriv_atanred_f32,
+// quadrant and special-value selects in the library's order.
+template <int NC>
+__device__ __forceinline__ void atan2_lib_vn(const f32x2 (&y)[NC], const f32x2 (&x)[NC], f32x2 (&o)[NC]) {
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 q[NC], t[NC], p[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        float qq[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float ax = fabsf(h ? x[c].y : x[c].x), ay = fabsf(h ? y[c].y : y[c].x);
+            const float v = __builtin_fminf(ax, ay), u = __builtin_fmaxf(ax, ay);
+            const float m = __builtin_amdgcn_frexp_mantf(v) * __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(u));
+            qq[h] = __builtin_amdgcn_ldexpf(m, __builtin_amdgcn_frexp_expf(v) - __builtin_amdgcn_frexp_expf(u));
+        }
+        q[c] = f32x2{qq[0], qq[1]};
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) t[c] = q[c] * q[c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(t[c], k2(__uint_as_float(0x3b2d2a58u)), k2(__uint_as_float(0xbc7a590cu)));
+    constexpr uint32_t co[6] = {0x3d29fb3fu, 0xbd97d4d7u, 0x3dd931b2u, 0xbe1160e6u, 0x3e4cb8bfu, 0xbeaaaa62u};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(t[c], p[c], k2(__uint_as_float(co[s])));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = t[c] * p[c];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) q[c] = __builtin_elementwise_fma(q[c], p[c], q[c]);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 t1 = k2(__uint_as_float(0x3fc90fdbu)) - q[c];
+        f32x2 a = {fabsf(y[c].x) > fabsf(x[c].x) ? t1.x : q[c].x, fabsf(y[c].y) > fabsf(x[c].y) ? t1.y : q[c].y};
+        const f32x2 t2 = k2(__uint_as_float(0x40490fdbu)) - a;
+        float r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float xe = h ? x[c].y : x[c].x, ye = h ? y[c].y : y[c].x;
+            float e = (xe < 0.0f) ? (h ? t2.y : t2.x) : (h ? a.y : a.x);
+            const float t3 = ((int)__float_as_uint(xe) < 0) ? __uint_as_float(0x40490fdbu) : 0.0f;
+            e = (ye == 0.0f) ? t3 : e;
+            const float t4 = (xe < 0.0f) ? __uint_as_float(0x4016cbe4u) : __uint_as_float(0x3f490fdbu);
+            e = (__builtin_isinf(xe) && __builtin_isinf(ye)) ? t4 : e;
+            e = (xe != xe || ye != ye) ? __uint_as_float(0x7fc00000u) : e;
+            r[h] = copysignf(e, ye);
+        }
+        o[c] = f32x2{r[0], r[1]};
+    }
+}
+
+// acosf of the device library (__ocml_acos_f32), with the constant folding hipcc applies to it (fma(c1, c2, -z) with
+// c1 * c2 = pi, pi / 2 becomes a subtraction from the rounded constant)
+template <int NC>
+__device__ __forceinline__ void acos_lib_vn(const f32x2 (&x)[NC], f32x2 (&o)[NC]) {
+    auto k2 = [](float c) { return f32x2{c, c}; };
+    f32x2 w[NC], p[NC];
+    bool big[NC][2];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 ax = {fabsf(x[c].x), fabsf(x[c].y)};
+        const f32x2 h = __builtin_elementwise_fma(ax, k2(-0.5f), k2(0.5f)), s = x[c] * x[c];
+        big[c][0] = ax.x > 0.5f; big[c][1] = ax.y > 0.5f;
+        w[c] = f32x2{big[c][0] ? h.x : s.x, big[c][1] ? h.y : s.y};
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(w[c], k2(__uint_as_float(0x3d1c21a7u)), k2(__uint_as_float(0x3c5fc5dau)));
+    constexpr uint32_t co[4] = {0x3d034c3cu, 0x3d3641b1u, 0x3d999bc8u, 0x3e2aaaacu};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) p[c] = __builtin_elementwise_fma(w[c], p[c], k2(__uint_as_float(co[s])));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const f32x2 z = w[c] * p[c];
+        const f32x2 sq = {__builtin_amdgcn_sqrtf(w[c].x), __builtin_amdgcn_sqrtf(w[c].y)};
+        const f32x2 g = __builtin_elementwise_fma(sq, z, sq);
+        const f32x2 g2 = g + g;
+        const f32x2 neg = k2(__uint_as_float(0x40490fdbu)) - g2;
+        const f32x2 sm = k2(__uint_as_float(0x3fc90fdbu)) - __builtin_elementwise_fma(x[c], z, x[c]);
+        o[c] = f32x2{big[c][0] ? (x[c].x < 0.0f ? neg.x : g2.x) : sm.x, big[c][1] ? (x[c].y < 0.0f ? neg.y : g2.y) : sm.y};
+    }
+}
+
+// dihedral4_ref for NC columns x two rows (the same operations per element in the same order)
+template <int NC>
+__device__ __forceinline__ void dihedral4v_ref_n(const f3v (&a)[NC], const f3v (&b)[NC], const f3v (&c)[NC],
+                                                 const f3v (&d)[NC], f32x2 (&out)[NC]) {
+    f32x2 x[NC], y0[NC], nb[NC], y[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const f3v b0 = sub3v(a[q], b[q]), b1 = sub3v(c[q], b[q]), b2 = sub3v(d[q], c[q]);
+        const f3v n1 = cross3v(b0, b1), n2 = cross3v(b2, b1);
+        const f3v m = cross3v(n1, n2);
+        x[q] = dot3v_f(n1, n2);
+        y0[q] = dot3v_f(m, b1);
+        nb[q] = sqrt_rn_mk_v((b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z);   // squares are never -0: dot3's leading `0 +` changes no bit
+    }
+    div_ieee_vn<NC>(y0, nb, y);
+    atan2_lib_vn<NC>(y, x, out);
+}
+
+// angle3_ref for NC columns x two rows
+template <int NC>
+__device__ __forceinline__ void angle3v_ref_n(const f3v (&a)[NC], const f3v (&b)[NC], const f3v (&c)[NC], f32x2 (&out)[NC]) {
+    f32x2 num[NC], den[NC], cs[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        const f3v ba = sub3v(a[q], b[q]), bc = sub3v(c[q], b[q]);
+        num[q] = dot3v_f(ba, bc);
+        den[q] = sqrt_rn_mk_v((ba.x * ba.x + ba.y * ba.y) + ba.z * ba.z) * sqrt_rn_mk_v((bc.x * bc.x + bc.y * bc.y) + bc.z * bc.z);
+    }
+    div_ieee_vn<NC>(num, den, cs);
+    acos_lib_vn<NC>(cs, out);
+}
+
 // geometry.gram_schmidt (geometry.py:428-439); e3 uses the last-axis cross
 __device__ __forceinline__ void gram_schmidt3(f3 a, f3 b, f3 c, f3& e1, f3& e2, f3& e3) {
     f3 v1 = sub3(c, b);

@@ -259,7 +259,7 @@ def set_exact_angles(flag: bool, device=None) -> None:
     where the reference is exact, otherwise within the conditioning gates (3.8e-6 of off-diagonal dihedrals more than
     1e-5 from the reference at unit scale).  True: geometry.dihedral / geometry.angle in the reference's order of
     operations (three cross products, division by |b1|, library atan2 / acos): no entry beyond 1e-5 on well-conditioned
-    inputs, about 2.5x the time.  ``PROTSTRUC_AMD_EXACT_ANGLES=1`` makes True the default of every device."""
+    inputs, on the same per-CU sweep kernels as the fast forms (DESIGN.md section 4 has both modes' times).  ``PROTSTRUC_AMD_EXACT_ANGLES=1`` makes True the default of every device."""
     _lib.set_exact_angles(flag, device)
 
 
@@ -409,8 +409,8 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
     """K3.  n_points = 4: dihedral, 3: planar angle, over points (slots_i of residue i ++ slots_j of residue j).
     Only residue rows [row_begin, row_end) are computed, with K1's row addressing: into rows [row_begin, row_end) of
     a full-size (B, N, N) buffer (``out`` may supply it, e.g. the destination of an all-gather) or, with ``compact``,
-    into a (B, row_end - row_begin, N) buffer.  ``_one_column`` (tests): the fast arithmetic through the simple one-column
-    kernel at any shape (``exact_angles = 2`` of the C ABI, diagnostic)."""
+    into a (B, row_end - row_begin, N) buffer.  ``_one_column`` (tests): the device's arithmetic (``set_exact_angles``)
+    through the simple one-column kernel at any shape (bit 1 of ``exact_angles`` of the C ABI, diagnostic)."""
     xyz = _f32c(xyz, "xyz")
     B, N, A = xyz.shape[:3]
     slots = [int(s) for s in slots_i] + [int(s) for s in slots_j]
@@ -432,12 +432,12 @@ def pairwise_angles(xyz: torch.Tensor, slots_i: Sequence[int], slots_j: Sequence
         if not (B == 0 or N == 0 or row_begin == row_end):   # empty input: nothing to launch (an empty tensor has no device pointer)
             rc = _lib.load().ps_pairwise_angles_f32(
                 _ptr(xyz), _ptr(out), B, N, A, n_points, arr(*src), arr(*slots), row_begin, row_end, out_rows, origin,
-                2 if _one_column else _lib.get_exact_angles(xyz.device), _stream(xyz))
+                _lib.get_exact_angles(xyz.device) | (2 if _one_column else 0), _stream(xyz))
     _lib.check(rc, "ps_pairwise_angles_f32")
     return out
 
 
-def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None):
+def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] = None, *, _one_column: bool = False):
     """Fused featuriser: dict of six (B,N,N) fp32 planes and three (B,N,N) bool planes.  The distance planes use the
     device's K1 square-root mode (``set_exact_sqrt``), so they equal the slices of ``pairwise_distance`` bit for bit."""
     xyz = _f32c(xyz, "xyz")
@@ -462,7 +462,7 @@ def inter_residue_geometry(xyz: torch.Tensor, atom_mask: Optional[torch.Tensor] 
             rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xyz), _ptr(m), *[fp + 4 * fstride * i for i in range(6)],
                                                            *[kp + kstride * i for i in range(3)], B, N, A,
                                                            _lib.get_tuning("k1_exact_sqrt", dev),
-                                                           _lib.get_exact_angles(dev), _stream(xyz))
+                                                           _lib.get_exact_angles(dev) | (2 if _one_column else 0), _stream(xyz))
     _lib.check(rc, "ps_inter_residue_geometry_f32")
     out = {key: f[i, :plane].view(B, N, N) for i, key in enumerate(fkeys)}
     out.update({key: k[i, :plane].view(B, N, N) for i, key in enumerate(mkeys)})

@@ -1021,6 +1021,51 @@ def test_k3_config3_shape(SB):
     assert torch.equal(geo["omega"].nan_to_num(0), sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]).nan_to_num(0))
 
 
+def test_k3_config3_shape_faithful_mode(SB):
+    """BASELINE config 3 (B=128, N=512) in the reference's order of operations (`set_exact_angles(True)`; north_star: "fp32
+    within 1e-5 abs, NaN positions identical"): full launches on the per-CU sweep kernels; on four structures NO dihedral --
+    diagonal included -- is more than 1e-5 from the oracle (angular distance; max <= 2e-6), the planar angle is within 1e-5
+    wherever the angle is more than 0.05 rad from 0 and pi (nearer, acos amplifies the last bits of the cosine -- a 3-ulp
+    difference between this division / square root chain and numpy's is 1.2e-5 at 0.015 rad) and within its conditioning gate everywhere; NaN positions are EQUAL to the
+    oracle's in all three; the featuriser's angle planes equal the K3 launches bit for bit."""
+    from protstruc_amd import ops
+    B, N = 128, 512
+    xyz, mask = synth(3, B, N)
+    sb = SB.from_xyz(xyz, mask)
+    pick = [0, 37, 64, 127]
+    same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
+    try:
+        ops.set_exact_angles(True)
+        outs = {}
+        for (key, ai, aj, si, sj, npts) in [("omega", ["CA", "CB"], ["CA", "CB"], [1, 4], [1, 4], 4), ("theta", ["N", "CA", "CB"], ["CB"], [0, 1, 4], [4], 4),
+                                            ("phi", ["CA", "CB"], ["CB"], [1, 4], [4], 3)]:
+            plan = __import__("protstruc_amd._lib", fromlist=["k3_plan"]).k3_plan(B, N, 15, si, sj, npts, exact_angles=1)
+            assert plan["family"] == "sweep" and plan["faithful"] == 1, plan
+            got = (sb.pairwise_dihedrals if npts == 4 else sb.pairwise_planar_angles)(ai, aj)
+            outs[key] = got
+            assert got.shape == (B, N, N)
+            g = got[pick].cpu()
+            ref = (O.pairwise_dihedrals if npts == 4 else O.pairwise_planar_angles)(xyz[pick], si, sj)
+            assert torch.equal(g.isnan(), ref.isnan()), key                      # NaN positions identical
+            ok = ~ref.isnan()
+            if npts == 4:
+                err = torch.minimum((g - ref).abs(), (2 * np.pi - (g - ref).abs()).abs())[ok]
+                assert (err > 1e-5).sum().item() == 0 and err.max().item() <= 2e-6, (key, err.max().item())
+                diag = torch.diagonal(g, dim1=1, dim2=2)
+                assert ((diag == 0) & ~torch.signbit(diag)).all()
+            else:
+                err = (g - ref).abs()
+                well = ok & ((ref - np.pi).abs() > 5e-2) & (ref.abs() > 5e-2)   # |cos| <= 1 - 1.25e-3: an ulp of the cosine moves the angle by <= 1.2e-6
+                assert (err[well] > 1e-5).sum().item() == 0, err[well].max().item()
+                assert (err[ok] > 1e-5).float().mean().item() <= 1e-4
+                assert torch.diagonal(g, dim1=1, dim2=2).isnan().all()
+        geo = sb.inter_residue_geometry()
+        for key in ("omega", "theta", "phi"):
+            assert same(geo[key], outs[key]), key
+    finally:
+        ops.set_exact_angles(False)
+
+
 def test_config5_shape_diffusion_loop(SB):
     """BASELINE config 5 shape (B=256, N=384): standardize once, then a short loop three ways --
     step-by-step, fused steps, and the LDS-resident trajectory kernel -- must agree bit for bit."""
@@ -1181,13 +1226,18 @@ def test_k3_row_ranges_compact_and_in_place(SB, N):
 
 
 # 140, 300, 330, 450: a last strip with one / one / two / three live column groups of 64 (the dead ones are skipped)
+@pytest.mark.parametrize("faithful", [False, True], ids=["fast", "faithful"])
 @pytest.mark.parametrize("N", [6, 64, 101, 130, 140, 255, 256, 300, 330, 384, 450, 511, 512, 516])
-def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
+def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N, faithful):
     """The per-CU sweep kernels (two / four column residues per lane, LDS-staged rows, pulled tasks, arithmetic
     interleaved across the columns) evaluate the same operations per pair as the one-column kernel: same bits.  The
     one-column kernel is asked for explicitly (`exact_angles = 2`, diagnostic); the dispatcher's pick for an aligned output
     (vector stores for even N, the 64-apart column layout with dword stores for odd N) and for a 4-byte-misaligned output
-    (always the dword layout; short chains: the one-column kernel) are both held to it; full launches and an odd row range."""
+    (always the dword layout; short chains: the one-column kernel) are both held to it; full launches and an odd row range.
+    `faithful`: the same in the reference's order of operations (`set_exact_angles(True)`, round 5): there the one-column
+    kernel CALLS the device library (atan2f, acosf, the compiler's IEEE division) per element while the sweep kernels run
+    the library's instruction sequences restated in packed form (ps_common.hpp: atan2_lib_vn, acos_lib_vn, div_ieee_vn) --
+    this identity is what pins the restatement to the library."""
     from protstruc_amd import ops
     B = 3
     xyz, _ = synth(900 + N, B, N)
@@ -1197,17 +1247,21 @@ def test_k3_sweep_kernels_bit_identical_to_the_one_column_kernel(SB, N):
     same = lambda a, b: torch.equal(a.isnan(), b.isnan()) and torch.equal(a.nan_to_num(5.0), b.nan_to_num(5.0))
     splits = [(4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (4, [2], [0, 1, 2]), (4, [1], [4, 1, 0]), (4, [0, 1], [2, 3]),
               (4, [0, 1, 2, 3], []), (4, [], [0, 1, 2, 3]), (3, [1, 4], [4]), (3, [1], [1, 4]), (3, [], [0, 1, 2]), (3, [4, 1, 0], [])]
-    for npts, si, sj in splits:
-        one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
-        big = torch.full((B * N * N + 1,), 7.0, device="cuda")
-        mis = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned: columns 64 apart, dword stores
-        fast = ops.pairwise_angles(xg, si, sj, npts)
-        assert same(fast, one) and same(mis, one), (npts, si, sj)
-        assert big[0] == 7.0
-        if N > 8:
-            r0, r1 = 3, N - 2                                                      # odd number of rows, odd first row
-            c = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True)
-            assert same(c, one[:, r0:r1]), (npts, si, sj)
+    try:
+        ops.set_exact_angles(faithful)
+        for npts, si, sj in splits:
+            one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
+            big = torch.full((B * N * N + 1,), 7.0, device="cuda")
+            mis = ops.pairwise_angles(xg, si, sj, npts, out=big[1:].view(B, N, N))      # misaligned: columns 64 apart, dword stores
+            fast = ops.pairwise_angles(xg, si, sj, npts)
+            assert same(fast, one) and same(mis, one), (npts, si, sj)
+            assert big[0] == 7.0
+            if N > 8:
+                r0, r1 = 3, N - 2                                                      # odd number of rows, odd first row
+                c = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True)
+                assert same(c, one[:, r0:r1]), (npts, si, sj)
+    finally:
+        ops.set_exact_angles(False)
 
 
 def test_k3_exact_angles_mode(SB):
@@ -1268,8 +1322,8 @@ def test_k3_exact_angles_mode(SB):
     import ctypes
     arr = (ctypes.c_int * 4)
     xg = xyz[:1].contiguous().cuda(); out = torch.empty(1, N, N, device="cuda")
-    rc = lib.ps_pairwise_angles_f32(xg.data_ptr(), out.data_ptr(), 1, N, 15, 4, arr(0, 0, 1, 1), arr(1, 4, 1, 4), 0, N, N, 0, 3, None)
-    assert rc == 1                                                        # exact_angles outside {0, 1, 2}: refused before any launch
+    rc = lib.ps_pairwise_angles_f32(xg.data_ptr(), out.data_ptr(), 1, N, 15, 4, arr(0, 0, 1, 1), arr(1, 4, 1, 4), 0, N, N, 0, 4, None)
+    assert rc == 1                                                        # exact_angles outside {0, 1, 2, 3}: refused before any launch
 
 
 def test_k3_planar_angle_collinear_and_extreme_arms(SB):
@@ -1357,6 +1411,7 @@ def test_k3_differential_fuzz(SB):
         if trial % 7 == 0 and N > 2:
             xyz[-1, 1] = xyz[-1, 0]
         xg = xyz.cuda()
+        ops.set_exact_angles(trial % 3 == 2)        # every third trial in the reference's order of operations
         one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
         if trial % 4 == 1:          # the misaligned-output path as well
             big = torch.full((B * N * N + 1,), 7.0, device="cuda")
@@ -1372,6 +1427,7 @@ def test_k3_differential_fuzz(SB):
             ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
             assert same(buf[:, r0:r1], one[:, r0:r1]), (trial, B, N, A, npts, si, sj, r0, r1)
             assert (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+    ops.set_exact_angles(False)
 
 
 @pytest.mark.parametrize("N", [1, 2, 3, 5, 8, 15, 16, 17, 31, 32, 33, 48, 63, 64])
@@ -1389,14 +1445,19 @@ def test_k3_short_chain_kernel_bit_identical_to_the_one_column_kernel(SB, N):
             xyz[0, N // 2] = float("nan")
             xyz[B - 1, 1] = xyz[B - 1, 0]
         xg = xyz.cuda()
-        for npts, si, sj in splits:
-            one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
-            assert same(ops.pairwise_angles(xg, si, sj, npts), one), (N, B, npts, si, sj)
-            r0, r1 = N // 3, N - N // 4
-            assert same(ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True), one[:, r0:r1])
-            buf = torch.full((B, N, N), 321.0, device="cuda")
-            ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
-            assert same(buf[:, r0:r1], one[:, r0:r1]) and (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+        for faithful in (False, True):               # the fast arithmetic, and the reference's order of operations
+            try:
+                ops.set_exact_angles(faithful)
+                for npts, si, sj in splits:
+                    one = ops.pairwise_angles(xg, si, sj, npts, _one_column=True)
+                    assert same(ops.pairwise_angles(xg, si, sj, npts), one), (N, B, npts, si, sj, faithful)
+                    r0, r1 = N // 3, N - N // 4
+                    assert same(ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=True), one[:, r0:r1])
+                    buf = torch.full((B, N, N), 321.0, device="cuda")
+                    ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, out=buf)
+                    assert same(buf[:, r0:r1], one[:, r0:r1]) and (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
+            finally:
+                ops.set_exact_angles(False)
 
 
 def test_k3_inside_a_captured_graph(SB):
@@ -1738,10 +1799,10 @@ def test_inter_residue_geometry_matches_unfused_kernels(SB, N):
     assert fm["d_ca_mask"].dtype == torch.float32 and torch.equal(fm["d_ca_mask"].bool(), geo["d_ca_mask"])
 
 
-def _featuriser_in_sentinels(xyz, mask, shifts, exact_sqrt=0):
+def _featuriser_in_sentinels(xyz, mask, shifts, exact_sqrt=0, faithful=0):
     """ps_inter_residue_geometry_f32 into planes placed `shifts` = [(6 float shifts in floats, 3 mask shifts in bytes), ...]
     away from their slots inside sentinel-filled buffers, each compared bit for bit with the one-column kernel
-    (exact_angles = 2: same arithmetic, the plain layout); no sentinel may change."""
+    (exact_angles = 2 | faithful: same arithmetic, the plain layout); no sentinel may change."""
     from protstruc_amd import _lib
     from protstruc_amd.ops import _ptr, _stream
     B, N = xyz.shape[:2]
@@ -1769,9 +1830,9 @@ def _featuriser_in_sentinels(xyz, mask, shifts, exact_sqrt=0):
         assert (fbuf[keepf] == 777.0).all() and (mbuf[keepm] == 7).all(), (N, B, mode, f_shift, m_shift)
         return fs, ms
 
-    ref_f, ref_m = run(2, [0] * 6, [0] * 3)
+    ref_f, ref_m = run(2 | faithful, [0] * 6, [0] * 3)
     for f_shift, m_shift in shifts:
-        fs, ms = run(0, f_shift, m_shift)
+        fs, ms = run(faithful, f_shift, m_shift)
         for k in range(6):
             assert torch.equal(fs[k].isnan(), ref_f[k].isnan()) and torch.equal(fs[k].nan_to_num(0), ref_f[k].nan_to_num(0)), (N, B, k, f_shift)
         for k in range(3):
@@ -1802,7 +1863,7 @@ def test_inter_residue_geometry_differential_fuzz(SB):
             mask_t = torch.ones(B, N, 15, dtype=torch.bool)
         else:
             mask_t = mask
-        _featuriser_in_sentinels(xyz, mask_t, [(fsh, msh)], exact_sqrt=trial % 2)
+        _featuriser_in_sentinels(xyz, mask_t, [(fsh, msh)], exact_sqrt=trial % 2, faithful=int(trial % 3 == 1))
 
 
 # ... 2048: the longest chain whose rows, column points and masks fit in LDS (158 KB); 2100: beyond it (one-column kernel)
@@ -1817,6 +1878,8 @@ def test_inter_residue_geometry_c_abi_inside_sentinels_any_alignment(SB, N, B):
     mask[0, N // 2] = False
     mask[B - 1, :, 4] = False            # a structure without CB
     _featuriser_in_sentinels(xyz, mask, [([0] * 6, [0] * 3), ([1, 2, 3, 0, 1, 2], [1, 5, 3]), ([0] * 6, [15, 8, 4])])
+    # ... and in the reference's order of operations (round 5: the same sweep, the library's sequences in packed form)
+    _featuriser_in_sentinels(xyz, mask, [([0] * 6, [0] * 3), ([1, 2, 3, 0, 1, 2], [1, 5, 3])], faithful=1)
 
 
 def test_fused_diffuse_frames(SB):
