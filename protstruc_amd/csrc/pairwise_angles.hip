@@ -394,7 +394,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
             } else {
                 // (not three of four, and nothing for the (2,2) dihedral at four columns: with those variants that instantiation
                 // spilled 3-5 registers)
-                constexpr bool SKIP = !(NP == 4 && SRC == 12 && NC == 4);
+                constexpr bool SKIP = FAITHFUL || !(NP == 4 && SRC == 12 && NC == 4);   // (the faithful kernels have 256 VGPRs)
                 const int ncl = SKIP ? min(NC, (N - strip * 64 * NC + 63) >> 6) : NC;   // live column groups of this strip (uniform)
                 if (!SKIP || ncl == NC || ncl == 3) K3_SWEEP_ROWS(NC)
                 else if (NC == 4 && ncl == 2) K3_SWEEP_ROWS((NC == 4 ? 2 : 1))

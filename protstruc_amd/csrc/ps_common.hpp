@@ -483,10 +483,11 @@ __device__ __forceinline__ f32x2 dist3v(f3v a, f3v b) {
 }
 
 // geometry.angle (geometry.py:64-71): no clamp before acos.  The reference divides the dot product by the product of
-// two norms; here cos = (ba . bc) * rsq((ba . ba) * (bc . bc)) -- one v_rsq_f32 (1 ulp) instead of two correctly rounded
-// square roots and an IEEE divide (3 instructions instead of ~29; the relative rounding error of the cosine is ~1.5 ulp
-// either way) -- and acos_ps above.  A zero-length arm (the diagonal of pairwise_planar_angles) is 0 * rsq(0) = 0 * inf
-// = NaN like the reference's 0 / 0; the squared lengths multiply without overflow up to 1e9 A arms.
+// two norms; here cos = ((ba . bc) * rsq(ba . ba)) * rsq(bc . bc) -- two v_rsq_f32 (1 ulp each) instead of two correctly
+// rounded square roots and an IEEE divide (4 instructions instead of ~29) -- and acos_ps above.  Each arm is scaled away
+// before the next factor comes in (round 5; rounds 3-4 multiplied the two squared lengths first, which overflowed for
+// arms beyond 4e9 and underflowed below 1e-10): any arm between 1e-19 and 1e19 is safe, as in the reference.  A
+// zero-length arm (the diagonal of pairwise_planar_angles) is 0 * rsq(0) = 0 * inf = NaN like the reference's 0 / 0.
 template <bool EXACT>
 __device__ __forceinline__ f32x2 dist3v_t(f3v a, f3v b) {
     const f32x2 dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
@@ -499,8 +500,8 @@ __device__ __forceinline__ f32x2 dist3v_t(f3v a, f3v b) {
 __device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
     const f3v ba = sub3v(a, b), bc = sub3v(c, b);
     const f32x2 num = dot3v(ba, bc);
-    const f32x2 q = dot3v(ba, ba) * dot3v(bc, bc);
-    return acos_ps_v(num * f32x2{__builtin_amdgcn_rsqf(q.x), __builtin_amdgcn_rsqf(q.y)});
+    const f32x2 na = dot3v(ba, ba), nb = dot3v(bc, bc);
+    return acos_ps_v((num * f32x2{__builtin_amdgcn_rsqf(na.x), __builtin_amdgcn_rsqf(na.y)}) * f32x2{__builtin_amdgcn_rsqf(nb.x), __builtin_amdgcn_rsqf(nb.y)});
 }
 
 template <int NC>
@@ -511,8 +512,8 @@ __device__ __forceinline__ void angle3v_n(const f3v (&a)[NC], const f3v (&b)[NC]
         const f3v ba = sub3v(a[q], b[q]), bc = sub3v(c[q], b[q]);
         const f32x2 num = dot3v_f(ba, bc);
         // squares are never -0, so the sums need no leading `0 +` (same bits as dot3v(ba, ba), dot3v(bc, bc))
-        const f32x2 den = ((ba.x * ba.x + ba.y * ba.y) + ba.z * ba.z) * ((bc.x * bc.x + bc.y * bc.y) + bc.z * bc.z);
-        cs[q] = num * f32x2{__builtin_amdgcn_rsqf(den.x), __builtin_amdgcn_rsqf(den.y)};
+        const f32x2 na = (ba.x * ba.x + ba.y * ba.y) + ba.z * ba.z, nb = (bc.x * bc.x + bc.y * bc.y) + bc.z * bc.z;
+        cs[q] = (num * f32x2{__builtin_amdgcn_rsqf(na.x), __builtin_amdgcn_rsqf(na.y)}) * f32x2{__builtin_amdgcn_rsqf(nb.x), __builtin_amdgcn_rsqf(nb.y)};
     }
     acos_ps_vn<NC>(cs, out);
 }
@@ -520,8 +521,7 @@ __device__ __forceinline__ void angle3v_n(const f3v (&a)[NC], const f3v (&b)[NC]
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     f3 ba = sub3(a, b);
     f3 bc = sub3(c, b);
-    const float q = dot3(ba, ba) * dot3(bc, bc);
-    return acos_ps(dot3(ba, bc) * __builtin_amdgcn_rsqf(q));
+    return acos_ps((dot3(ba, bc) * __builtin_amdgcn_rsqf(dot3(ba, ba))) * __builtin_amdgcn_rsqf(dot3(bc, bc)));
 }
 
 // ---- the FAITHFUL forms for NC columns x two rows (round 5): dihedral4_ref / angle3_ref bit for bit, packed ----

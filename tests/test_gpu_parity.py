@@ -989,7 +989,7 @@ def test_k3_vs_oracle_conditioning_gate(SB, ai, aj, npts):
     assert (err_vs_ref > 1e-5).float().mean().item() <= 1e-4
     e_got = wrap(got.double() - truth)[sel]
     e_ref = wrap(ref.double() - truth)[sel]
-    assert e_got.max().item() <= max(4 * e_ref.max().item(), 2e-5)
+    assert e_got.max().item() <= max(2 * e_ref.max().item(), 2e-5)   # (SURVEY hard part 3: "no worse than"; measured <= 1.6x, profiles/r05_k3_error_stats.log)
     assert (e_got > 1e-5).float().mean().item() <= (e_ref > 1e-5).float().mean().item() + 1e-4
     # NaNs only where the reference has them, up to |cos| rounding just past 1 (acos without clamp)
     nan_mismatch = (torch.isnan(got) != torch.isnan(ref))[off].float().mean().item()
@@ -1013,7 +1013,14 @@ def test_k3_config3_shape(SB):
         ok = off & ~(ref.isnan() | g.isnan())
         wrap = (lambda d: torch.minimum(d.abs(), (2 * np.pi - d.abs()).abs())) if npts == 4 else (lambda d: d.abs())
         assert (wrap(g - ref)[ok] > 1e-5).float().mean().item() <= 1e-4
-        assert wrap(g.double() - truth)[ok].max().item() <= max(4 * wrap(ref.double() - truth)[ok].max().item(), 2e-5)
+        # against fp64: the MAXIMUM over 10^6 entries is one tail event of each arithmetic's own ill-conditioning pattern (the
+        # fast form's worst entry is not the oracle's worst entry), so the maxima are held to 4x (measured 3.4x here, 1.6x at
+        # N = 192 where test_k3_vs_oracle_conditioning_gate holds them to 2x) and the 1 - 1e-5 quantiles -- ten entries
+        # from the top, a statistic rather than an event -- to 2x
+        e_got, e_ref = wrap(g.double() - truth)[ok], wrap(ref.double() - truth)[ok]
+        assert e_got.max().item() <= max(4 * e_ref.max().item(), 2e-5)
+        kth = max(1, int(e_got.numel() * (1 - 1e-5)))
+        assert e_got.kthvalue(kth).values.item() <= max(2 * e_ref.kthvalue(kth).values.item(), 1e-5)
         diag = torch.diagonal(g, dim1=1, dim2=2)
         assert ((diag == 0) & ~torch.signbit(diag)).all() if npts == 4 else diag.isnan().all()
     geo = sb.inter_residue_geometry()
@@ -1327,11 +1334,13 @@ def test_k3_exact_angles_mode(SB):
 
 
 def test_k3_planar_angle_collinear_and_extreme_arms(SB):
-    """Where the fast planar angle (cos = dot * rsq(|ba|^2 |bc|^2), polynomial acos) may leave the reference, pinned:
-    exactly collinear points (the reference's correctly rounded division gives cos = -1 or 1 exactly -> pi or 0; one ulp of
-    v_rsq_f32 puts the fast cosine at 1 -+ 6e-8 -> within 4e-4 of it or NaN), arms of 1e10 (the product of the squared
-    lengths overflows: rsq(inf) = 0 -> pi / 2) and of 1e-12 (it underflows: NaN).  Documented in INTEGRATION.md; the
-    faithful mode (`set_exact_angles(True)`) has none of the three and equals the oracle to 1e-6."""
+    """Where the fast planar angle (cos = dot * rsq(|ba|^2) * rsq(|bc|^2), polynomial acos) may leave the reference, pinned:
+    exactly collinear points (the reference's correctly rounded division gives cos = -1 or 1 exactly -> pi or 0; an ulp of
+    v_rsq_f32 puts the fast cosine at 1 -+ 6e-8 -> within 5e-4 of it or NaN).  Documented in INTEGRATION.md.  Extreme arm
+    lengths are NOT such a case any more (round 5: each arm's reciprocal length is applied before the next factor comes in;
+    rounds 3-4 multiplied the squared lengths first, which overflowed at 1e10 -> pi / 2 and underflowed at 1e-12 -> NaN):
+    arms of 1e10 and of 1e-12 give the angles of the unit-scale configuration.  The faithful mode
+    (`set_exact_angles(True)`) equals the oracle to 1e-6 everywhere, collinear points included."""
     from protstruc_amd import ops
     A = 5
     xyz = torch.zeros(1, 4, A, 3)
@@ -1351,8 +1360,10 @@ def test_k3_planar_angle_collinear_and_extreme_arms(SB):
     tiny = xyz.clone(); tiny[0, :, :, :] *= 1e-12
     fb = SB.from_xyz(big).pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
     ft = SB.from_xyz(tiny).pairwise_planar_angles(["CA", "CB"], ["CB"])[0, 0].cpu()
-    assert abs(fb[3].item() - np.pi / 2) <= 1e-6 and (fb[1].item() == pytest.approx(np.pi / 2, abs=1e-6) or fb[1].isnan())   # overflow: documented
-    assert ft[1].isnan() or abs(ft[1].item() - np.pi) <= 5e-4                                                          # underflow: documented
+    for f in (fb, ft):                                     # scale-free: the unit-scale answers at 1e10 and at 1e-12
+        assert abs(f[3].item() - np.pi / 2) <= 1e-6
+        assert f[1].isnan() or abs(f[1].item() - np.pi) <= 5e-4
+        assert f[2].isnan() or abs(f[2].item()) <= 5e-4
     try:
         ops.set_exact_angles(True)
         for x in (xyz, big, tiny):
@@ -1458,6 +1469,145 @@ def test_k3_short_chain_kernel_bit_identical_to_the_one_column_kernel(SB, N):
                     assert same(buf[:, r0:r1], one[:, r0:r1]) and (buf[:, :r0] == 321.0).all() and (buf[:, r1:] == 321.0).all()
             finally:
                 ops.set_exact_angles(False)
+
+
+def _angle_gates(got, ref, npts, faithful, where):
+    """The parity gates of a K3 plane against the oracle (SURVEY hard part 3).  fast: >= 1 - 1e-4 of the off-diagonal entries
+    within 1e-5 (angular distance), NaN positions equal up to 1e-5 of entries (|cos| rounding just past 1); faithful: NO
+    dihedral beyond 1e-5 anywhere and NaN positions EQUAL; the faithful planar angle within 1e-5 wherever the angle is
+    more than 0.05 rad from 0 and pi, and inside the 1e-4 gate everywhere."""
+    n = ref.shape[-1]
+    off = ~torch.eye(n, dtype=torch.bool).expand_as(ref) if ref.shape[-2] == n else torch.ones_like(ref, dtype=torch.bool)
+    d = (got - ref).abs()
+    err = torch.minimum(d, (2 * np.pi - d).abs()) if npts == 4 else d
+    both = ~(got.isnan() | ref.isnan())
+    slack = 2.0 / max(1, int((both & off).sum()))                 # short chains: one ill-conditioned entry is allowed
+    if faithful:
+        assert torch.equal(got.isnan(), ref.isnan()), where
+        if npts == 4:
+            assert (err[both] > 1e-5).sum().item() == 0, (where, err[both].max().item())
+        else:
+            well = both & ((ref - np.pi).abs() > 5e-2) & (ref.abs() > 5e-2)
+            assert (err[well] > 1e-5).sum().item() == 0, (where, err[well].max().item())
+            assert (err[both] > 1e-5).float().mean().item() <= 1e-4 + slack, where
+    else:
+        assert (err[both & off] > 1e-5).float().mean().item() <= 1e-4 + slack, (where, (err[both & off] > 1e-5).float().mean().item())
+        assert (got.isnan() != ref.isnan())[off].float().mean().item() <= 1e-5 + slack, where
+
+
+def _picks(B, N):
+    return sorted({0, B // 3, (2 * B) // 3, B - 1}) if N < 1000 else [0]
+
+
+def _k3_table_ids():
+    from tests.k3_families import K3_SHAPES
+    return [e for e in K3_SHAPES if e[8]]
+
+
+@pytest.mark.parametrize("entry", _k3_table_ids(), ids=lambda e: f"B{e[0]}-N{e[1]}-np{e[2][0]}-i{len(e[2][1])}-mis{e[5]}-mode{e[6]}")
+def test_k3_every_dispatch_arm_vs_oracle(SB, entry):
+    """tests/k3_families.py: one launch per arm of K3's dispatcher (k3_small at 16 / 32 padded columns; the sweep at four / two
+    columns per lane, adjacent or 64 apart, dead column groups skipped or not, one or two workgroups per CU; the one-column
+    kernel; each in both arithmetic modes).  tests/test_k3_plan.py (CPU) holds the table to the dispatcher; here each entry is
+    launched through the C ABI into a sentinel-framed buffer at the alignment the entry names, the plan of THAT launch
+    (actual address, this device's CU count) must be the arm the table names, and the result is held to the ORACLE."""
+    import ctypes
+    from protstruc_amd import _lib, ops
+    from tests.k3_families import K3_ARM_KEYS, arm_key
+    B, N, (npts, si, sj), rows, compact, mis, mode, want, _ = entry
+    r0, r1 = rows if rows else (0, N)
+    xyz, _m = synth(8800 + N + B, B, N)
+    xg = xyz.cuda()
+    out_rows = (r1 - r0) if compact else N
+    pad = 64
+    big = torch.full((B * out_rows * N + 2 * pad + 4,), 777.0, device="cuda")
+    base = pad + ((mis - big.data_ptr() % 16) % 16) // 4
+    out = big[base:base + B * out_rows * N].view(B, out_rows, N)
+    assert out.data_ptr() % 16 == mis
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    plan = _lib.k3_plan(B, N, 15, si, sj, npts, r0, r1, compact=compact, out_misalign=mis, exact_angles=mode, cu_count=cus)
+    if cus == 256:
+        assert arm_key(plan, K3_ARM_KEYS) == tuple(want[k] for k in K3_ARM_KEYS), plan
+    try:
+        ops.set_exact_angles(bool(mode & 1))
+        got = ops.pairwise_angles(xg, si, sj, npts, row_begin=r0, row_end=r1, compact=compact, out=out, _one_column=bool(mode & 2))
+    finally:
+        ops.set_exact_angles(False)
+    torch.cuda.synchronize()
+    assert got is out
+    assert (big[:base] == 777.0).all() and (big[base + B * out_rows * N:] == 777.0).all(), "a sentinel around the output changed"
+    lo = 0 if compact else r0
+    if not compact:
+        assert (out[:, :r0] == 777.0).all() and (out[:, r1:] == 777.0).all(), "rows outside the requested range were written"
+    assert not (out[:, lo:lo + (r1 - r0)] == 777.0).any(), "part of the requested rows was not written"
+    pick = _picks(B, N)
+    ref = (O.pairwise_dihedrals if npts == 4 else O.pairwise_planar_angles)(xyz[pick], si, sj)[:, r0:r1]
+    g = out[pick][:, lo:lo + (r1 - r0)].cpu()
+    _angle_gates(g, ref, npts, bool(mode & 1), (B, N, npts, si, sj, mode, plan["kernel"]))
+
+
+def _featuriser_table_ids():
+    from tests.k3_families import FEATURISER_SHAPES
+    return [e for e in FEATURISER_SHAPES if e[6]]
+
+
+@pytest.mark.parametrize("entry", _featuriser_table_ids(), ids=lambda e: f"B{e[0]}-N{e[1]}-f{e[2]}-m{e[3]}-mode{e[4]}")
+def test_featuriser_every_dispatch_arm_vs_oracle(SB, entry):
+    """tests/k3_families.py: one launch per arm of the featuriser's dispatcher (four / two columns per lane, vector / dword
+    float stores, strip-local / flat mask stores, write-through or not, one or two workgroups per CU, the one-column kernel;
+    both arithmetic modes), through the C ABI into sentinel-framed planes at the alignment the entry names, each plane held
+    to the ORACLE: distances <= 1e-5, masks exact, angles by the gates of `_angle_gates`."""
+    from protstruc_amd import _lib
+    from protstruc_amd.ops import _ptr, _stream
+    from tests.k3_families import FEATURISER_ARM_KEYS, arm_key
+    B, N, fmis, mmis, mode, want, _ = entry
+    xyz, mask = synth(9900 + N + B, B, N)
+    mask[0, N // 2] = False
+    xg, mg = xyz.cuda(), mask.cuda().to(torch.uint8)
+    plane, pad = B * N * N, 256
+    fbuf = torch.full((6 * (plane + pad) + pad,), 777.0, device="cuda")
+    mbuf = torch.full((3 * (plane + pad) + pad,), 7, dtype=torch.uint8, device="cuda")
+    # plane k of the six / three starts at the entry's misalignment (modulo 128) -- the first plane exactly, the others too
+    foff = [pad + i * (plane + pad) for i in range(6)]
+    foff = [o + ((fmis - (fbuf.data_ptr() + 4 * o) % 128) % 128) // 4 for o in foff]
+    moff = [pad + i * (plane + pad) for i in range(3)]
+    moff = [o + (mmis - (mbuf.data_ptr() + o) % 128) % 128 for o in moff]
+    alf = 0
+    for o in foff:
+        alf |= (fbuf.data_ptr() + 4 * o) % 128
+    alm = 0
+    for o in moff:
+        alm |= (mbuf.data_ptr() + o) % 128
+    assert alf == fmis and alm == mmis
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    plan = _lib.featuriser_plan(B, N, 15, float_misalign=alf, mask_misalign=alm, exact_angles=mode, cu_count=cus)
+    if cus == 256:
+        assert arm_key(plan, FEATURISER_ARM_KEYS) == tuple(want[k] for k in FEATURISER_ARM_KEYS), plan
+    rc = _lib.load().ps_inter_residue_geometry_f32(_ptr(xg), _ptr(mg), *[fbuf.data_ptr() + 4 * o for o in foff],
+                                                   *[mbuf.data_ptr() + o for o in moff], B, N, 15, 0, mode, _stream(xg))
+    assert rc == 0
+    torch.cuda.synchronize()
+    keepf = torch.ones_like(fbuf, dtype=torch.bool)
+    keepm = torch.ones_like(mbuf, dtype=torch.bool)
+    for o in foff:
+        keepf[o:o + plane] = False
+    for o in moff:
+        keepm[o:o + plane] = False
+    assert (fbuf[keepf] == 777.0).all() and (mbuf[keepm] == 7).all(), "a sentinel between the planes changed"
+    pick = _picks(B, N)
+    refd = O.inter_residue_geometry(xyz[pick][:, :, :5].contiguous(), mask[pick][:, :, :5].contiguous())   # slots N, CA, C, O, CB only
+    names = ["d_ca", "d_cb", "d_no", "omega", "theta", "phi"]
+    for k, name in enumerate(names):
+        g = fbuf[foff[k]:foff[k] + plane].view(B, N, N)[pick].cpu()
+        assert not (g == 777.0).any(), name
+        where = (B, N, mode, name, plan["kernel"])
+        if name.startswith("d_"):
+            assert torch.equal(g.isnan(), refd[name].isnan()) and (g - refd[name]).abs().nan_to_num(0).max().item() <= 1e-5, where
+        else:
+            _angle_gates(g, refd[name], 3 if name == "phi" else 4, bool(mode & 1), where)
+    for k, name in enumerate(["d_ca_mask", "d_cb_mask", "d_no_mask"]):
+        g = mbuf[moff[k]:moff[k] + plane].view(B, N, N)[pick].cpu()
+        assert torch.equal(g.bool(), refd[name].bool()) and int(g.max()) <= 1, (B, N, mode, name)
 
 
 def test_k3_inside_a_captured_graph(SB):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/k1_traffic.json (what bench.py reports as roofline.traffic) from the two counter passes of
-tools/gpu_profile_r03.sh:  python3 tools/make_k1_traffic.py <bench_pmc_w.json> <bench_pmc_f.json> <out.json> <round>
+tools/gpu_profile_rNN.sh:  python3 tools/make_k1_traffic.py <bench_pmc_w.json> <bench_pmc_f.json> <out.json> <round> [script]
 
 WRITE_SIZE and FETCH_SIZE are reported in KiB; FETCH_SIZE is doubled (MI355X_MICROARCH.md: gfx950 reports half of wide
 coalesced reads).  A bench process launches the pattern kernel with every tile length the tuner tries
@@ -11,6 +11,7 @@ import re
 import sys
 
 w, f, out, rnd = sys.argv[1:5]
+script = sys.argv[5] if len(sys.argv) > 5 else f"tools/gpu_profile_r{int(rnd):02d}.sh"
 B, N, A = 64, 512, 15
 alg = B * N * N * A * A * 5
 
@@ -34,7 +35,7 @@ for k in sorted(set(ws) & set(fs)):
                   "ratio_to_algorithmic": (wb + 2 * fb) / alg, "dispatches_averaged": {"WRITE_SIZE": nw, "FETCH_SIZE": nf}}
 res = {"B": B, "N_res": N, "N_atom": A, "algorithmic_bytes_per_launch": alg, "kernels": kernels,
        "source": f"round {rnd}: rocprofv3 --output-format csv --pmc WRITE_SIZE / --pmc FETCH_SIZE (separate passes) on "
-                 "`python3 bench.py --no-cpu-baseline --steps 3` (tools/gpu_profile_r03.sh); counter unit KiB; FETCH_SIZE "
+                 f"`python3 bench.py --no-cpu-baseline --steps 3` ({script}); counter unit KiB; FETCH_SIZE "
                  "doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); mean over the dispatches of "
                  "each kernel at the headline grid in the process (tuner candidates, warm-up, timed)"}
 json.dump(res, open(out, "w"), indent=1)

@@ -2,7 +2,7 @@
 """Workloads for rocprofv3 (run as `rocprofv3 ... -- python3 tools/profile_workload.py <what> [reps]`):
 
     k3      BASELINE config 3 (B=128, N_res=512): pairwise_dihedrals (2,2) CA,CB|CA,CB and (3,1) N,CA,CB|CB,
-            pairwise_planar_angles (2,1) CA,CB|CB, and the fused inter_residue_geometry
+            pairwise_planar_angles (2,1) CA,CB|CB, and the fused inter_residue_geometry -- in both arithmetic modes
     k1a     K1 at atom14 (N=256) and atom37 (N=128), ~8 GB of output each: default dispatch (fixed-A flat pattern
             kernel / row-phase kernel) and the row-phase kernel forced (k1_rowphase=1)
     k1      the headline K1 launch (B=64, N=512, A=15)
@@ -44,10 +44,13 @@ def repeat(fn):
 if what == "k3":
     xyz, mask = synth(128, 512)
     sb = StructureBatch.from_xyz(xyz, mask)
-    repeat(lambda: sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]))
-    repeat(lambda: sb.pairwise_dihedrals(["N", "CA", "CB"], ["CB"]))
-    repeat(lambda: sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
-    repeat(lambda: sb.inter_residue_geometry())
+    for faithful in (False, True):      # the fast arithmetic, then the reference's order of operations (kernel names differ: FAITHFUL)
+        ops.set_exact_angles(faithful)
+        repeat(lambda: sb.pairwise_dihedrals(["CA", "CB"], ["CA", "CB"]))
+        repeat(lambda: sb.pairwise_dihedrals(["N", "CA", "CB"], ["CB"]))
+        repeat(lambda: sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
+        repeat(lambda: sb.inter_residue_geometry())
+    ops.set_exact_angles(False)
 elif what == "k5":
     xyz, mask = synth(256, 384)
     sb = StructureBatch.from_xyz(xyz, mask).manual_seed(1)

@@ -4,6 +4,8 @@
     python3 tools/summarize_rocprof.py stats <dir> <out.csv>      # *_kernel_stats.csv of a --kernel-trace --stats run
     python3 tools/summarize_rocprof.py pmc <dir> <out.json> [skip] # *_counter_collection.csv of a --pmc run
     python3 tools/summarize_rocprof.py pmcseq <dir> <out.json> <kernel substring>   # the same, one entry per DISPATCH, in order
+    python3 tools/summarize_rocprof.py ranges <dir> <out.json> <bench line file>    # kernel trace of a bench.py run, cut at the
+                                                                                    # K1 dispatch ordinals the line reports
 
 `pmc` sums every counter over the dispatches of each kernel (after dropping the first `skip` dispatches of each
 kernel: warm-ups; default 2), and reports per-kernel per-dispatch means.  Counter units are left as rocprofv3 reports
@@ -96,11 +98,46 @@ def trace(d, out, kernel_substr, last_k):
         json.dump(res, fh, indent=1)
 
 
+def ranges(d, out, bench_json, prefix="k1_"):
+    """Cut the kernel trace of a bench.py process at the dispatch ordinals its result line reports
+    (roofline.k1_dispatch_ordinals_timed_region and allocation_lottery.kept_pair_timed_like_the_headline.k1_dispatch_ordinals):
+    the n-th dispatch whose kernel name starts with `prefix` is the n-th K1 launch of the process."""
+    rows = []
+    for f in find(d, "kernel_trace.csv"):
+        with open(f) as fh:
+            rows += [r for r in csv.DictReader(fh) if short(r["Kernel_Name"]).startswith(prefix)]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    with open(bench_json) as fh:
+        line = [l for l in fh.read().splitlines() if l.startswith("{") and '"metric"' in l][-1]
+    res_line = json.loads(line)
+    roof = res_line["roofline"]
+    cuts = {"timed_region": roof["k1_dispatch_ordinals_timed_region"]}
+    kept = roof.get("allocation_lottery", {}).get("kept_pair_timed_like_the_headline", {})
+    if "k1_dispatch_ordinals" in kept:
+        cuts["kept_pair_timed_like_the_headline"] = kept["k1_dispatch_ordinals"]
+    res = {"k1_dispatches_in_trace": len(rows), "nbytes_per_launch": roof["algorithmic_bytes_per_launch"]}
+    for name, (a, b) in cuts.items():
+        sel = rows[a:b]
+        ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel]
+        res[name] = {"dispatch_ordinals": [a, b], "kernels": sorted({short(r["Kernel_Name"]) for r in sel}),
+                     "grids": sorted({int(r["Grid_Size"]) for r in sel}),
+                     "mean_ms": sum(ms) / len(ms) if ms else None, "min_ms": min(ms) if ms else None, "max_ms": max(ms) if ms else None,
+                     "frac_of_hbm_peak_at_the_trace_mean": (roof["algorithmic_bytes_per_launch"] / (sum(ms) / len(ms) * 1e-3) / 8e12) if ms else None}
+    res["timed_region"]["bench_line_kernel_ms_hip_events"] = roof["kernel_ms"]
+    res["timed_region"]["buffer_fill_GBps"] = roof.get("buffer_fill_GBps")
+    if "kept_pair_timed_like_the_headline" in res:
+        res["kept_pair_timed_like_the_headline"]["bench_line_kernel_ms_hip_events"] = kept.get("kernel_ms")
+    with open(out, "w") as fh:
+        json.dump(res, fh, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]))
+    elif sys.argv[1] == "ranges":
+        ranges(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "pmcseq":
         pmcseq(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
