@@ -175,23 +175,80 @@ __device__ __forceinline__ float dihedral4(f3 a, f3 b, f3 c, f3 d) {
 
 // ---- the FAITHFUL forms (round 4): geometry.dihedral / geometry.angle op for op in the reference's order ----
 // What `exact_angles` of ps_pairwise_angles_f32 / ps_inter_residue_geometry_f32 selects, as `exact_sqrt` does for K1: three
-// cross products, y divided by |b1| (correctly rounded square root, IEEE division), the device library's atan2f / acosf
-// (<= 2 ulp; the reference's np.arctan2 / torch.arccos are libm-grade as well) -- no algebraic rewriting, no reciprocal
-// square roots, no polynomials of this file.  About 2.5x the instructions of the fast forms.
+// cross products, y divided by |b1| (correctly rounded square root, IEEE division), atan2 / acos in the device library's
+// arithmetic (<= 2 ulp; the reference's np.arctan2 / torch.arccos are libm-grade as well) -- no algebraic rewriting, no
+// reciprocal square roots, no polynomials of this file.
+//
+// atan2_lib / acos_lib (round 5) ARE the device library's atan2f / acosf (ROCm 7.2 ocml: __ocml_atan2_f32 with its
+// __ocmlpriv_atanred_f32, __ocml_acos_f32; denormals on, finite-only off), written out instruction for instruction as hipcc
+// -O3 emits a call of them on gfx950 -- read off ocml.bc's IR and the ISA of a one-line kernel -- instead of being called.
+// Why not call them: the library asks for its v / u division with `!fpmath 2.5 ulp`, and whether the compiler then emits
+// the cheap form (frexp mantissas, v_rcp_f32, v_ldexp_f32) or a full IEEE division turned out to depend on the CALL SITE
+// (inside a loop body: the cheap form; hoisted out of a loop whose operands are all loop-invariant -- K3 with every point
+// from the column residue -- the IEEE form): two kernels calling atan2f on the same arguments disagreed in the last bit on
+// 13 % of them.  Written with builtins the sequence is the same everywhere; it is the cheap form, which is what a plain
+// call gives, and tools/microbench/libm_identity.hip holds it to such calls over 2^32 argument pairs (0 mismatches,
+// profiles/r05_libm_identity.log).
+__device__ __forceinline__ float atan2_lib(float y, float x) {
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float v = __builtin_fminf(ax, ay), u = __builtin_fmaxf(ax, ay);
+    const float m = __builtin_amdgcn_frexp_mantf(v) * __builtin_amdgcn_rcpf(__builtin_amdgcn_frexp_mantf(u));
+    const float q = __builtin_amdgcn_ldexpf(m, __builtin_amdgcn_frexp_expf(v) - __builtin_amdgcn_frexp_expf(u));
+    const float t = q * q;
+    float p = __builtin_fmaf(t, __uint_as_float(0x3b2d2a58u), __uint_as_float(0xbc7a590cu));
+    p = __builtin_fmaf(t, p, __uint_as_float(0x3d29fb3fu));
+    p = __builtin_fmaf(t, p, __uint_as_float(0xbd97d4d7u));
+    p = __builtin_fmaf(t, p, __uint_as_float(0x3dd931b2u));
+    p = __builtin_fmaf(t, p, __uint_as_float(0xbe1160e6u));
+    p = __builtin_fmaf(t, p, __uint_as_float(0x3e4cb8bfu));
+    p = __builtin_fmaf(t, p, __uint_as_float(0xbeaaaa62u));
+    p = t * p;
+    float a = __builtin_fmaf(q, p, q);
+    const float t1 = __uint_as_float(0x3fc90fdbu) - a;
+    a = ay > ax ? t1 : a;
+    const float t2 = __uint_as_float(0x40490fdbu) - a;
+    a = x < 0.0f ? t2 : a;
+    const float t3 = ((int)__float_as_uint(x) < 0) ? __uint_as_float(0x40490fdbu) : 0.0f;
+    a = (y == 0.0f) ? t3 : a;
+    const float t4 = (x < 0.0f) ? __uint_as_float(0x4016cbe4u) : __uint_as_float(0x3f490fdbu);
+    a = (__builtin_isinf(x) && __builtin_isinf(y)) ? t4 : a;
+    a = (x != x || y != y) ? __uint_as_float(0x7fc00000u) : a;
+    return copysignf(a, y);
+}
+
+__device__ __forceinline__ float acos_lib(float x) {
+    const float ax = fabsf(x);
+    const float h = __builtin_fmaf(ax, -0.5f, 0.5f), s = x * x;
+    const bool big = ax > 0.5f;
+    const float w = big ? h : s;
+    float p = __builtin_fmaf(w, __uint_as_float(0x3d1c21a7u), __uint_as_float(0x3c5fc5dau));
+    p = __builtin_fmaf(w, p, __uint_as_float(0x3d034c3cu));
+    p = __builtin_fmaf(w, p, __uint_as_float(0x3d3641b1u));
+    p = __builtin_fmaf(w, p, __uint_as_float(0x3d999bc8u));
+    p = __builtin_fmaf(w, p, __uint_as_float(0x3e2aaaacu));
+    const float z = w * p;
+    const float sq = __builtin_amdgcn_sqrtf(w);
+    const float g = __builtin_fmaf(sq, z, sq);
+    const float g2 = g + g;
+    const float neg = __uint_as_float(0x40490fdbu) - g2;
+    const float sm = __uint_as_float(0x3fc90fdbu) - __builtin_fmaf(x, z, x);
+    return big ? (x < 0.0f ? neg : g2) : sm;
+}
+
 __device__ __forceinline__ float dihedral4_ref(f3 a, f3 b, f3 c, f3 d) {
     const f3 b0 = sub3(a, b), b1 = sub3(c, b), b2 = sub3(d, c);
     const f3 n1 = cross3(b0, b1);          // np.cross(b0, b1)
     const f3 n2 = cross3(b2, b1);          // np.cross(b2, b1)
     const f3 m = cross3(n1, n2);
     const float x = dot3(n1, n2);
-    const float y = dot3(m, b1) / norm3(b1);
-    return atan2f(y, x);
+    const float y = dot3(m, b1) / norm3(b1);   // an IEEE division: correctly rounded, hence the same bits however it is lowered
+    return atan2_lib(y, x);
 }
 
 __device__ __forceinline__ float angle3_ref(f3 a, f3 b, f3 c) {
     const f3 ba = sub3(a, b), bc = sub3(c, b);
     const float cosine = dot3(ba, bc) / (norm3(ba) * norm3(bc));
-    return acosf(cosine);                  // no clamp, as geometry.py:64-71
+    return acos_lib(cosine);               // no clamp, as geometry.py:64-71
 }
 
 // atan2 of the PAIRWISE kernels (K3 and the fused featuriser; K2 and the pointwise entry keep atan2_ps with every IEEE
@@ -525,14 +582,12 @@ __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
 }
 
 // ---- the FAITHFUL forms for NC columns x two rows (round 5): dihedral4_ref / angle3_ref bit for bit, packed ----
-// dihedral4_ref / angle3_ref above call the device library (atan2f, acosf) and the compiler's IEEE division once per
-// element: ~150 unpacked VALU instructions per dihedral.  What follows are the SAME operations, instruction for
-// instruction as hipcc (ROCm 7.2, -O3 -ffp-contract=off) emits them for those calls on gfx950 -- read off the ISA of a
-// one-line kernel per function and off ocml.bc's IR -- with the multiplies, adds and fused multiply-adds of two rows issued
-// as one v_pk_*_f32 and the NC columns' dependent chains interleaved.  An IEEE fma / mul / add gives the same bits whether
-// it issues as v_fma_f32 or as half of v_pk_fma_f32, so the results equal the library's bit for bit; that equality is
-// not assumed but tested: tests/test_gpu_parity.py holds these kernels to the one-column kernel (which calls the
-// library) on every split, length and special value, and tools/microbench/libm_identity.hip sweeps 2^32 argument pairs.
+// The same operations as dihedral4_ref / angle3_ref (atan2_lib, acos_lib, the IEEE division), with the multiplies, adds and
+// fused multiply-adds of two rows issued as one v_pk_*_f32 and the NC columns' dependent chains interleaved.  An IEEE fma /
+// mul / add gives the same bits whether it issues as v_fma_f32 or as half of v_pk_fma_f32, so the results equal the scalar
+// forms' bit for bit; that equality is not assumed but tested: tests/test_gpu_parity.py holds the sweep kernels (these
+// forms) to the one-column kernel (the scalar forms) on every split, length and special value, and
+// tools/microbench/libm_identity.hip sweeps 2^32 argument pairs through both and through the library calls.
 //
 // a / b, IEEE-correct: the expansion of fdiv (v_div_scale_f32 x2, v_rcp_f32, the Newton / residual chain, v_div_fmas_f32,
 // v_div_fixup_f32); the chain's six operations packed.
@@ -566,9 +621,7 @@ __device__ __forceinline__ void div_ieee_vn(const f32x2 (&a)[NC], const f32x2 (&
                      __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(t[c].y, r[c].y, q[c].y, fy[c]), b[c].y, a[c].y)};
 }
 
-// atan2f of the device library (__ocml_atan2_f32 with denormals on, finite-only off): v / u of min / max by the 2.5-ulp
-// division the library asks for (frexp mantissas, v_rcp_f32, v_ldexp_f32), the degree-8 odd polynomial __ocmlpriv_atanred_f32,
-// quadrant and special-value selects in the library's order.
+// atan2_lib on NC columns x two rows
 template <int NC>
 __device__ __forceinline__ void atan2_lib_vn(const f32x2 (&y)[NC], const f32x2 (&x)[NC], f32x2 (&o)[NC]) {
     auto k2 = [](float c) { return f32x2{c, c}; };
@@ -622,8 +675,8 @@ __device__ __forceinline__ void atan2_lib_vn(const f32x2 (&y)[NC], const f32x2 (
     }
 }
 
-// acosf of the device library (__ocml_acos_f32), with the constant folding hipcc applies to it (fma(c1, c2, -z) with
-// c1 * c2 = pi, pi / 2 becomes a subtraction from the rounded constant)
+// acos_lib on NC columns x two rows (the library's fma(c1, c2, -z) with c1 * c2 = pi, pi / 2 is, as hipcc folds it, a
+// subtraction from the rounded constant)
 template <int NC>
 __device__ __forceinline__ void acos_lib_vn(const f32x2 (&x)[NC], f32x2 (&o)[NC]) {
     auto k2 = [](float c) { return f32x2{c, c}; };

@@ -1,6 +1,6 @@
-// The packed restatements of the device library's atan2f / acosf and of the compiler's IEEE division
-// (ps_common.hpp: atan2_lib_vn, acos_lib_vn, div_ieee_vn -- what the FAITHFUL sweep kernels of K3 run) against the
-// library calls themselves, bit for bit:
+// The restatements of the device library's atan2f / acosf and of the compiler's IEEE division (ps_common.hpp: the scalar
+// atan2_lib / acos_lib of the one-column kernels and the packed atan2_lib_vn / acos_lib_vn / div_ieee_vn of the FAITHFUL
+// sweep kernels of K3) against the library calls themselves, bit for bit:
 //   acosf:   every one of the 2^32 float bit patterns;
 //   atan2f:  2^32 (y, x) pairs -- a quarter with both words uniformly random bit patterns (NaN, inf, subnormals, huge exponent
 //            gaps included), a quarter with |y| / |x| within 2^-8 .. 2^8 (where the polynomial works), a quarter with one
@@ -70,7 +70,15 @@ __global__ __launch_bounds__(256) void check(int what, unsigned long long* bad, 
                 want = f32x2{y0 / x0, y1 / x1};
             }
         }
-        const bool b0 = !same_bits(got[0].x, want.x), b1 = !same_bits(got[0].y, want.y);
+        // the scalar restatements (what the one-column kernels run) against the same calls
+        f32x2 sc;
+        if (what == 0) sc = f32x2{acos_lib(__uint_as_float(i0)), acos_lib(__uint_as_float(i1))};
+        else {
+            float y0, x0, y1, x1;
+            pair_of(i0, y0, x0); pair_of(i1, y1, x1);
+            sc = what == 1 ? f32x2{atan2_lib(y0, x0), atan2_lib(y1, x1)} : want;
+        }
+        const bool b0 = !same_bits(got[0].x, want.x) || !same_bits(sc.x, want.x), b1 = !same_bits(got[0].y, want.y) || !same_bits(sc.y, want.y);
         if (b0 || b1) {
             if (n_bad == 0 && atomicAdd(reinterpret_cast<unsigned*>(first), 1u) < 8u) {
                 const unsigned slot = atomicAdd(reinterpret_cast<unsigned*>(first) + 1, 1u);
