@@ -229,9 +229,10 @@ int ps_pairwise_angles_f32(const float* xyz, float* out,
 typedef struct ps_k3_plan {
     int struct_size;            /* in: sizeof(ps_k3_plan) */
     int n_launches;             /* 0 (empty input) or 1 */
-    char family[32];            /* "sweep" | "small" | "one_column" (K3); "featurise" | "one_column" (featuriser); "empty" */
+    char family[32];            /* "sweep" | "flat" | "flat_rows" | "small" | "one_column" (K3); "featurise" | "one_column" (featuriser); "empty" */
     char kernel[96];            /* kernel name with its template arguments, e.g. "k3_sweep<NP=4,SRC=12,NC=4,VEC=1,FAITHFUL=0>" */
-    int columns_per_lane;       /* sweep / featurise: 2 or 4 column residues per lane; small: the padded chain length (16 / 32); else 1 */
+    int columns_per_lane;       /* sweep / featurise: 2 or 4 column residues per lane; flat: elements (row pair, column) per lane;
+                                   small: the padded chain length (16 / 32); else 1 */
     int vector_stores;          /* 1: the lane's columns are adjacent (8- / 16-byte stores); 0: 64 apart (dword stores, any N) */
     int skips_dead_groups;      /* 1: dead 64-column groups of a row's last strip are not evaluated */
     int mask_store_mode;        /* featuriser: 2 strip-local 16-byte stores, 1 flat 16-byte stores, 0 bytes (one-column) */
@@ -239,7 +240,7 @@ typedef struct ps_k3_plan {
     int faithful;               /* bit 0 of exact_angles */
     int rows_per_task;          /* rows of one pulled task (sweep / featurise); rows per workgroup otherwise */
     int workgroups_per_cu;      /* 1 or 2 for the per-CU kernels (their LDS request pins it), 0: not pinned */
-    int structures_per_segment; /* sweep / featurise: structures staged together (short chains), else 0 */
+    int structures_per_segment; /* sweep / featurise: 1; flat: structures staged in LDS together; else 0 */
     unsigned n_workgroups;
     int threads_per_workgroup;
     unsigned lds_bytes;         /* static + dynamic LDS per workgroup */

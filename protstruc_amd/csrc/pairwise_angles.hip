@@ -88,6 +88,8 @@ constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-
 // nothing spilled: tools/kernel_resources.sh; same-box A/B at config 3 against two columns at 1024 threads: 80 / 66 / 43 us against
 // 83 / 74 / 48, profiles/r05_k3_modes_first.log)
 constexpr bool K3_FAITHFUL_NC4(int, int) { return true; }
+// the fast flat kernel at four elements per lane where the instantiation keeps its registers (128 VGPRs at 1024 threads)
+constexpr bool K3_FLAT_NC4(int NP, int SRC) { return true; }
 // threads of a full-width sweep workgroup: four waves per SIMD with 128 VGPRs each -- two with 256 for the faithful chains at
 // four columns per lane (the library-order chains keep ~2x the values live)
 constexpr int k3_sweep_threads(int NC, bool FAITHFUL) { return FAITHFUL && NC == 4 ? 512 : 1024; }
@@ -210,6 +212,168 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
             const int ia = i0 + 2 * h * G, ib = ia + G;
             if (live_j && ia < row_end) ob[(size_t)(ia - out_row_origin) * N + j] = v[h].x;
             if (live_j && ib < row_end) ob[(size_t)(ib - out_row_origin) * N + j] = v[h].y;
+        }
+    }
+}
+
+// Chains of 33 .. ~100 residues (round 5): FLAT over (row pair, column), several structures per staging pass.
+// The per-CU sweep gives a wave a strip of 64 * NC columns of ONE structure: below ~100 residues most lanes of a strip have no
+// column, a (structure, strip) segment has fewer tasks than the workgroup has waves, and every segment costs two barriers and
+// a round trip to L2 (N = 64: 143 us at 2^25 pairs, which is why such chains stayed with the one-column kernel: 85 us).  Here
+//   * a lane's element is a flat index f = row pair * N + column of one structure (64 consecutive f per store instruction, NC
+//     of them 64 apart per lane, their chains interleaved): every lane has work whatever N is;
+//   * the selected atoms of KS structures are staged at once (column-side atoms as {x, y, z, -} per (atom, residue), row-side
+//     atoms pair-interleaved as {x0, x1, y0, y1}, {z0, z1, -, -} per (row pair, atom): every read in the loop is 16 bytes),
+//     so the two barriers and the load latency of a pass are paid once per KS * N * N pairs instead of once per 4 096;
+//   * TWO 512-thread workgroups share a CU and a workgroup's share takes four or more passes: at these lengths the input is
+//     2.8 bytes per pair (N = 64) against 4 written, and while one workgroup waits for its next structures the other computes
+//     (one 1024-thread workgroup that staged its whole share first: 74 us at N = 64, of which ~20 were that wait; a plain
+//     coalesced copy of the coordinates instead of the gather of the selected atoms: 88 us -- it reads all 15 atoms);
+//   * both sides of a pair come from LDS per lane: lanes of one row pair read the same address (a broadcast), the column side
+//     is consecutive 16-byte words (no bank conflict);
+//   * tasks of 64 * NC flat elements are pulled from an LDS counter, as in the sweep; stores are unconditional (a dead
+//     element's offset lies beyond the buffer descriptor's range and the hardware drops it), so the NC chains stay in one
+//     basic block and interleave.
+// Same arithmetic per pair as the one-column kernel: same bits.
+template <int NP, int SRC, int NC, bool FAITHFUL, bool ROWMAJOR>
+__global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
+                                                AtomSel sel, int row_begin, int row_end, int out_rows,
+                                                int out_row_origin, int KS, unsigned tps, unsigned n_tasks,
+                                                unsigned tasks_per_wg, unsigned rcpN, int col_vec4, int slot_vec4) {
+    static_assert(NC == 2 || NC == 4, "elements per lane");
+    constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
+    constexpr int NPIq = NPI > 0 ? NPI : 1, NPJq = NPJ > 0 ? NPJ : 1;
+    // [structure slot][column part: (atom, residue) -> {x, y, z, -} | row part: (row pair, atom) -> {x0, x1, y0, y1}, {z0, z1, -, -}]
+    extern __shared__ __attribute__((aligned(16))) k3_f32x4 k3_flatbuf[];
+    __shared__ unsigned next_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned n_waves = blockDim.x >> 6;
+    const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
+    if (t0 >= t1) return;                         // whole workgroup
+    int amap_i[NPIq], amap_j[NPJq];
+    {
+        int qi = 0, qj = 0;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            if ((SRC >> k) & 1) amap_j[qj++] = sel.atom[k];
+            else amap_i[qi++] = sel.atom[k];
+        }
+        if (NPI == 0) amap_i[0] = 0;
+        if (NPJ == 0) amap_j[0] = 0;
+    }
+    const int rows = row_end - row_begin, n_rp = (rows + 1) >> 1;
+    const unsigned F = (unsigned)n_rp * (unsigned)N;   // flat elements (row pair, column) of one structure
+    const unsigned b_first = t0 / tps, b_last = (t1 - 1u) / tps;
+    for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS) {
+        const unsigned ks = min((unsigned)KS, b_last - bs + 1u);
+        __syncthreads();                                          // the previous pass's readers are done
+        for (unsigned it = threadIdx.x; it < ks * (unsigned)N; it += blockDim.x) {   // one residue of one structure per thread
+            unsigned s = __umulhi(it, rcpN), r = it - s * (unsigned)N;
+            if (r >= (unsigned)N) ++s, r -= (unsigned)N;
+            const float* pr = xyz + ((size_t)(bs + s) * N + r) * (size_t)A * 3;
+            k3_f32x4* slot = k3_flatbuf + (size_t)s * slot_vec4;
+            float vj[NPJq * 3], vi[NPIq * 3];
+#pragma unroll
+            for (int q = 0; q < NPJ; ++q) { vj[q * 3] = pr[amap_j[q] * 3]; vj[q * 3 + 1] = pr[amap_j[q] * 3 + 1]; vj[q * 3 + 2] = pr[amap_j[q] * 3 + 2]; }
+            const int rr = (int)r - row_begin;
+            const bool in_rows = NPI > 0 && rr >= 0 && rr < rows;
+            if (in_rows) {
+#pragma unroll
+                for (int q = 0; q < NPI; ++q) { vi[q * 3] = pr[amap_i[q] * 3]; vi[q * 3 + 1] = pr[amap_i[q] * 3 + 1]; vi[q * 3 + 2] = pr[amap_i[q] * 3 + 2]; }
+            }
+#pragma unroll
+            for (int q = 0; q < NPJ; ++q) slot[q * N + (int)r] = k3_f32x4{vj[q * 3], vj[q * 3 + 1], vj[q * 3 + 2], 0.0f};
+            if (in_rows) {
+                float* rb = reinterpret_cast<float*>(slot + col_vec4) + (size_t)(rr >> 1) * (NPI * 8) + (rr & 1);
+#pragma unroll
+                for (int q = 0; q < NPI; ++q) { rb[q * 8] = vi[q * 3]; rb[q * 8 + 2] = vi[q * 3 + 1]; rb[q * 8 + 4] = vi[q * 3 + 2]; }
+            }
+        }
+        const unsigned seg_t0 = max(t0, bs * tps), seg_t1 = min(t1, (bs + ks) * tps);
+        if (threadIdx.x == 0) next_task = seg_t0 + n_waves;       // the first n_waves tasks are pre-assigned
+        __syncthreads();
+        unsigned t = seg_t0 + (unsigned)wave;
+        while (t < seg_t1) {
+            const unsigned b = t / tps, chunk = t - b * tps;      // (uniform)
+            const k3_f32x4* slot = k3_flatbuf + (size_t)(b - bs) * slot_vec4;
+            const k3_f32x4* rowp = slot + col_vec4;
+            float* obase = out + ((size_t)b * out_rows + (size_t)(row_begin - out_row_origin)) * N;
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, rows * N * 4, 0x00020000u);   // this structure's rows, exactly
+            // ROWMAJOR (N <= 64): the lane is column `lane` and its NC elements are NC consecutive row pairs -- no per-lane index
+            // arithmetic at all, the row side is one uniform address per element and what depends on the column alone is
+            // shared by the NC chains.  Otherwise: NC elements 64 apart in the flat index
+            const unsigned f0 = ROWMAJOR ? chunk * (unsigned)NC * (unsigned)N : chunk * (unsigned)(64 * NC);
+            // the task's first element on the scalar unit; a lane's elements follow by at most two wraps per 64 (N >= 32)
+            const unsigned rp0 = ROWMAJOR ? chunk * (unsigned)NC : f0 / (unsigned)N, j0 = ROWMAJOR ? 0u : f0 - rp0 * (unsigned)N;
+            auto run = [&](auto l_tag) {
+                constexpr int L = decltype(l_tag)::value;
+                f3v P[NP][L];
+                int off[L];
+                bool live[L], two[L];
+                int j = ROWMAJOR ? min(lane, N - 1) : (int)j0 + lane, rp = (int)rp0;
+#pragma unroll
+                for (int c = 0; c < L; ++c) {
+                    if constexpr (ROWMAJOR) {
+                        rp = (int)rp0 + c;
+                        live[c] = lane < N && rp < n_rp;
+                    } else {
+                        if (c > 0) j += 64;
+#pragma unroll
+                        for (int w = 0; w < 2; ++w) {
+                            const bool wrap = j >= N;
+                            j = wrap ? j - N : j;
+                            rp = wrap ? rp + 1 : rp;
+                        }
+                        live[c] = f0 + (unsigned)(c * 64 + lane) < F;
+                    }
+                    const int rpc = min(rp, n_rp - 1);            // dead elements read a live address and store nothing
+                    off[c] = (int)__umul24((unsigned)(2 * rpc), (unsigned)N) * 4 + j * 4;
+                    two[c] = 2 * rpc + 1 < rows;
+                    int qi = 0, qj = 0;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if ((SRC >> k) & 1) {
+                            const k3_f32x4 pj = slot[qj * N + j];
+                            P[k][c] = mk3v(f3{pj.x, pj.y, pj.z}, f3{pj.x, pj.y, pj.z});
+                            ++qj;
+                        } else {
+                            const k3_f32x4 xy = rowp[(rpc * NPI + qi) * 2];
+                            const f32x2 z = *reinterpret_cast<const f32x2*>(rowp + (rpc * NPI + qi) * 2 + 1);
+                            P[k][c] = f3v{f32x2{xy.x, xy.y}, f32x2{xy.z, xy.w}, z};
+                            ++qi;
+                        }
+                    }
+                }
+                f32x2 v[L];
+                if constexpr (NP == 4 && FAITHFUL)
+                    dihedral4v_ref_n<L>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (NP == 4)
+                    dihedral4v_k3_n<L>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (FAITHFUL)
+                    angle3v_ref_n<L>(P[0], P[1], P[2], v);
+                else
+                    angle3v_n<L>(P[0], P[1], P[2], v);
+                // results pinned before the stores (or the compiler sinks each chain into its own store's branch and the chains no
+                // longer interleave); the stores themselves are unconditional: a dead element's offset lies beyond the buffer's
+                // num_records and the hardware range check drops it
+#pragma unroll
+                for (int c = 0; c < L; ++c) asm volatile("" : "+v"(v[c]));
+#pragma unroll
+                for (int c = 0; c < L; ++c) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c].x), rsrc, live[c] ? off[c] : 0x7FFFFFF0, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c].y), rsrc, (live[c] && two[c]) ? off[c] + N * 4 : 0x7FFFFFF0, 0, 0);
+                }
+            };
+            // live elements per lane of this task (uniform; > 0): 64-element groups, or row pairs
+            const unsigned ngr = ROWMAJOR ? (unsigned)n_rp - rp0 : (F - f0 + 63u) >> 6;
+            if (ngr >= (unsigned)NC) run(std::integral_constant<int, NC>{});
+            else if (NC == 4 && ngr == 3u) run(std::integral_constant<int, NC == 4 ? 3 : 1>{});
+            else if (NC == 4 && ngr == 2u) run(std::integral_constant<int, NC == 4 ? 2 : 1>{});
+            else run(std::integral_constant<int, 1>{});
+            unsigned nx = 0;
+            if (lane == 0) nx = atomicAdd(&next_task, 1u);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
     }
 }
@@ -901,6 +1065,52 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
                  xyz, out, N, A, sel, row_begin, row_end, out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
 }
 
+// LDS the flat kernel stages its structures in (one workgroup per CU: the request keeps a second one off the CU)
+constexpr size_t K3_FLAT_LDS = 128 * 1024;
+
+template <int NP, int SRC, int NC, bool FAITHFUL, bool ROWMAJOR>
+int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end, int out_rows,
+                int out_row_origin, const K3Go& go) {
+    constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
+    const int rows = row_end - row_begin, rp = (rows + 1) / 2;
+    const unsigned long long F = (unsigned long long)rp * N;
+    // tasks per structure: NC elements per lane -- 64 apart in the flat index, or (ROWMAJOR) NC row pairs of the lane's column
+    const unsigned tps = ROWMAJOR ? (unsigned)((rp + NC - 1) / NC) : (unsigned)((F + 64 * NC - 1) / (64 * NC));
+    const unsigned long long n_tasks = (unsigned long long)tps * B;
+    if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+    const int col_vec4 = NPJ * N, slot_vec4 = col_vec4 + rp * NPI * 2;   // 16-byte units: {x, y, z, -} per column atom; two per row-pair atom
+#ifdef PS_K3_AB
+    static const int wgs_env = getenv("PS_K3_FLAT_WGS") ? atoi(getenv("PS_K3_FLAT_WGS")) : 2;
+    static const int passes_env = getenv("PS_K3_FLAT_PASSES") ? atoi(getenv("PS_K3_FLAT_PASSES")) : 4;
+#else
+    constexpr int wgs_env = 2, passes_env = 4;
+#endif
+    // two 512-thread workgroups per CU (their LDS requests admit exactly two): one computes while the other stages
+    const int wgs = wgs_env == 1 ? 1 : 2;
+    const unsigned slots = (unsigned)go.cus * (unsigned)wgs;
+    const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + slots - 1) / slots, 4ull);
+    const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+    // structures per staging pass: a quarter of a workgroup's share (so that the two workgroups of a CU interleave their
+    // passes), at most what the LDS holds
+    const size_t lds_cap = wgs == 2 ? K3_LDS_TWO_PER_CU : K3_FLAT_LDS;
+    const unsigned share = (tasks_per_wg + tps - 1) / tps + 1;
+    const size_t by_share = std::max<size_t>(1, (share + passes_env - 1) / passes_env);
+    const int KS = (int)std::max<size_t>(1, std::min<size_t>(lds_cap / ((size_t)slot_vec4 * 16), by_share));
+    const size_t dyn = wgs == 2 ? K3_LDS_TWO_PER_CU : std::max((size_t)KS * slot_vec4 * 16, K3_LDS_ONE_PER_CU);
+    static unsigned long long prepared[1] = {0};
+    char name[96];
+    snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,NC=%d,FAITHFUL=%d,ROWMAJOR=%d>", NP, SRC, NC, (int)FAITHFUL, (int)ROWMAJOR);
+    K3Shape sh;
+    sh.nc = NC; sh.skips = 1; sh.faithful = FAITHFUL; sh.rows_per_task = ROWMAJOR ? 2 * NC : 0; sh.wgs_per_cu = wgs; sh.structs_per_segment = KS;
+    sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
+    return k3_go(go, ROWMAJOR ? "flat_rows" : "flat", name, sh, k3_flat<NP, SRC, NC, FAITHFUL, ROWMAJOR>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
+                 row_end, out_rows, out_row_origin, KS, tps, (unsigned)n_tasks, tasks_per_wg, (unsigned)((1ull << 32) / (unsigned)N), col_vec4,
+                 slot_vec4);
+}
+
+// whether one structure's selected atoms fit the flat kernel's LDS (two workgroups per CU)
+inline bool k3_flat_fits(int N, int) { return (size_t)N * 4 * 16 + (size_t)((N + 1) / 2) * 4 * 32 <= K3_LDS_TWO_PER_CU; }
+
 // One-column kernels: a workgroup as wide as the chain needs (whole waves, at most 256 lanes) -- with 256 lanes for a
 // 64-residue chain three of four waves computed pairs that do not exist.
 inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63) / 64); }
@@ -913,6 +1123,9 @@ constexpr int K3_SWEEP_MIN_N = 100;
 // ... the featuriser's sweep (tasks of two rows, a structure's column points in LDS, two workgroups per CU) pays from 64 on:
 // same-box trace at 2^25 pairs, sweep / one-column kernel: N = 99 314 / 361 us, 80 344 / 365, 64 280 / 300, 48 387 / 354, 33 645 / 474
 constexpr int K3_FEATURISE_MIN_N = 64;
+constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
+constexpr int K3_FLAT_UTIL_PERCENT = 78; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
+constexpr int K3_FLAT_UTIL_PERCENT_FAITHFUL = 90;   // (the faithful sweeps, two waves per SIMD, lose more to idle lanes: N = 160 149 us against ~110)
 constexpr int K3_SMALL_MAX_N = 32;    // k3_small: one wave per structure (33..64 measured: no better than the one-column kernel)
 
 template <int NP, int SRC, bool FAITHFUL>
@@ -937,7 +1150,12 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
            int out_rows, int out_row_origin, bool simple, unsigned out_misalign, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1));
     const int rows = row_end - row_begin;
-    if (!simple && N <= K3_SMALL_MAX_N) {   // short chains: lanes = (row group, column), one wave per structure
+#ifdef PS_K3_AB
+    static const int small_max = getenv("PS_K3_SMALL_MAX") ? atoi(getenv("PS_K3_SMALL_MAX")) : K3_SMALL_MAX_N;
+#else
+    constexpr int small_max = K3_SMALL_MAX_N;
+#endif
+    if (!simple && N <= small_max) {   // short chains: lanes = (row group, column), one wave per structure
         const unsigned long long n_wg = ((unsigned long long)B + 3) / 4;
         if (n_wg > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
         char name[96];
@@ -959,8 +1177,11 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
 #ifdef PS_K3_AB
     static const int force_nc = getenv("PS_K3_NC") ? atoi(getenv("PS_K3_NC")) : 0;
     const bool allow4 = force_nc != 2;
+    static const int flat_util = getenv("PS_K3_FLAT_UTIL") ? atoi(getenv("PS_K3_FLAT_UTIL")) : (FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT);
+    static const int rows_min = getenv("PS_K3_ROWMAJOR_MIN") ? atoi(getenv("PS_K3_ROWMAJOR_MIN")) : K3_FLAT_ROWS_MIN_N;
 #else
     const bool allow4 = true;
+    constexpr int flat_util = FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT, rows_min = K3_FLAT_ROWS_MIN_N;
 #endif
     const bool ok4 = NC4 && allow4 && fits && N % 4 == 0 && (out_misalign & 15u) == 0, ok2 = fits && N % 2 == 0 && (out_misalign & 7u) == 0;
     // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
@@ -969,16 +1190,31 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     // where the vector layouts compute whole strips -- taken also for even N where that saves more than its dword stores cost
     const long long gn = (N + 63) / 64, gv = (NC4 && ok4 && (!ok2 || w4 <= w2) ? w4 : w2) / 64;
     constexpr bool SKIPS = FAITHFUL || !(NP == 4 && SRC == 12);   // (the fast (2,2) dihedral's four-column instantiation evaluates every group: registers)
-    if ((ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100)) {
+    // the sweep layout this launch would take: vector stores or columns 64 apart, columns per lane, and the 64-column groups
+    // it evaluates per row pair (dead ones included unless skipped)
+    const bool vec = (ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100);
+    const int nc = vec ? ((NC4 && ok4 && (!ok2 || w4 <= w2)) ? 4 : 2) : ((NC4 && allow4 && (SKIPS ? gn > 2 : w4 <= w2)) ? 4 : 2);
+    const long long g_eval = vec ? gv : (SKIPS ? gn : (nc == 4 ? w4 : w2) / 64);
+    // The flat kernel (every lane has an element whatever N is; ~70 us per 2^25 pairs at any length, profiles/r05_k3_shapes.log):
+    // every chain shorter than the sweeps' minimum, and up to 256 residues wherever fewer than K3_FLAT_UTIL_PERCENT of the
+    // sweep's lanes would have a column (N = 140: three groups of 64 for 140 columns, 69 against 102 us; the fast (2,2) dihedral
+    // at N = 160: four groups, 68 against 86).  Its column-per-lane map from 57 to 64 residues (70 against 77 us at N = 64).
+    if (!simple && N > small_max && N >= 32 && k3_flat_fits(N, A) &&
+        (N < K3_SWEEP_MIN_N || !fits || (N <= 256 && (long long)N * 100 < (long long)flat_util * 64 * g_eval))) {
+        if (N >= rows_min && N <= 64)
+            return launch_flat<NP, SRC, 4, FAITHFUL, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
+        return launch_flat<NP, SRC, 4, FAITHFUL, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
+    }
+    if (vec) {
         if constexpr (NC4) {
-            if (ok4 && (!ok2 || w4 <= w2))
+            if (nc == 4)
                 return launch_sweep<NP, SRC, 4, true, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
         }
         return launch_sweep<NP, SRC, 2, true, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
     }
     if (fits) {   // odd N, a misaligned output, or fewer groups: the same sweep with the lane's columns 64 apart and dword stores
         if constexpr (NC4) {   // four columns from three groups on where dead groups are skipped; else by the lanes a strip wastes
-            if (allow4 && (SKIPS ? gn > 2 : w4 <= w2))
+            if (nc == 4)
                 return launch_sweep<NP, SRC, 4, false, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
         }
         return launch_sweep<NP, SRC, 2, false, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);

@@ -1,6 +1,6 @@
 #!/usr/bin/python3
 """K3 across chain lengths at a fixed number of residue pairs (2^25): the dispatcher's pick (per-CU sweep kernels for even N)
-against the one-column kernel (reached through a 4-byte-misaligned output), HIP events over a train of launches.
+against the one-column kernel (bit 1 of exact_angles), HIP events over a train of launches; PS_K3_FAITHFUL=1: the reference's order of operations.
    python3 tools/k3_shapes.py [reps] [N ...]"""
 import os
 import sys
@@ -8,7 +8,10 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from protstruc_amd import ops
+from protstruc_amd import _lib, ops
+
+if os.environ.get("PS_K3_FAITHFUL"):
+    ops.set_exact_angles(True)
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 
@@ -32,11 +35,10 @@ for N in ([int(v) for v in sys.argv[2:]] or [512, 384, 256, 200, 128, 100, 64, 4
     g = torch.Generator().manual_seed(N)
     xyz = torch.randn(B, N, 15, 3, generator=g).cuda()
     out = torch.empty(B, N, N, device="cuda")
-    big = torch.empty(B * N * N + 1, device="cuda")
-    mis = big[1:].view(B, N, N)
     row = f"N={N:4d} B={B:6d}  "
     for npts, si, sj in ((4, [1, 4], [1, 4]), (4, [0, 1, 4], [4]), (3, [1, 4], [4])):
         a = timed(lambda: ops.pairwise_angles(xyz, si, sj, npts, out=out))
-        b = timed(lambda: ops.pairwise_angles(xyz, si, sj, npts, out=mis))
-        row += f"  {a:6.1f} (one-column {b:6.1f})"
+        b = timed(lambda: ops.pairwise_angles(xyz, si, sj, npts, out=out, _one_column=True))
+        fam = _lib.k3_plan(B, N, 15, si, sj, npts, exact_angles=int(ops.get_exact_angles()))["family"]
+        row += f"  {a:6.1f} {fam} (one-column {b:6.1f})"
     print(row, flush=True)
