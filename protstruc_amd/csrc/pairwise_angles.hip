@@ -682,7 +682,7 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN) {
+    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, int KS, int slot_bytes) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
     static_assert(!M16 || VEC, "16-byte strip mask stores ride on the vector kernels");
     constexpr int POL = WT ? 16 : 0;
@@ -694,43 +694,54 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
     const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
     if (t0 >= t1) return;                         // whole workgroup
     const int max_pairs = (N + 2) / 2, Np = (N + 3) & ~3;
-    uint32_t* rowmask = reinterpret_cast<uint32_t*>(k3_rowbuf + (size_t)max_pairs * 9);   // per row pair: byte 0 = row 2r, byte 1 = row 2r + 1; bits n = 1, ca = 2, cb = 4
-    float* colpts = reinterpret_cast<float*>(reinterpret_cast<char*>(k3_rowbuf) + (((size_t)max_pairs * (9 * 8 + 4) + 32 + 15) & ~(size_t)15));   // [CA, O, CB][xyz][Np] (the row mask words have 8 spare)
-    // M16: colmask[plane][column] as bytes; !M16: colbits[plane][word] = the column masks as bit sets (planes CA, CB, O;
-    // zero beyond N and two zero words of padding).  Same region, 16-byte aligned.
-    uint8_t* colmask = reinterpret_cast<uint8_t*>(colpts + 9 * Np);
-    uint32_t* colbits = reinterpret_cast<uint32_t*>(colmask);
+    // one structure's slot: [row pair][N, CA, CB][xyz] as f32x2; the row mask words (per row pair: byte 0 = row 2r, byte 1 = row
+    // 2r + 1; bits n = 1, ca = 2, cb = 4; 8 spare); the column points [CA, O, CB][xyz][Np]; the column masks -- M16:
+    // colmask[plane][column] as bytes; !M16: colbits[plane][word] = bit sets (planes CA, CB, O; zero beyond N and two zero
+    // words of padding), same region, 16-byte aligned.  KS slots of slot_bytes each (round 5: several structures per staging
+    // pass -- short chains paid two barriers and a round trip to L2 per 4 096 pairs).
+    const size_t colpts_off = ((size_t)max_pairs * (9 * 8 + 4) + 32 + 15) & ~(size_t)15;
     const int nw = (N + 31) / 32 + 2;
     const int row_bytes = N * 4;
-    int staged_b = -1, staged_lo = -1, staged_hi = -1;
     // tasks of one structure: (chunk of CH rows, strip), a chunk's strips adjacent.  (Tried: a chunk of two rows x ALL strips,
     // the wave walking the strips inside the row pair, so that every 64-byte segment two stores share is completed by one
     // wave within a trip: 3-7 % SLOWER than four-row tasks per strip, N = 500 267 against 259 us -- the column points then
     // come from LDS every trip.  Two-row tasks per strip are what helped: see the launcher.)
     const int tpc = n_strips;                                         // tasks per chunk
     const unsigned n_sub = (unsigned)n_chunks * (unsigned)tpc;
-    for (unsigned b = t0 / n_sub; b <= (t1 - 1u) / n_sub; ++b) {       // the structures of this workgroup's tasks
-        const int c_lo = (int)(max(t0, b * n_sub) - b * n_sub);
-        const int c_hi = (int)(min(t1, (b + 1u) * n_sub) - b * n_sub);
-        const int r_lo = (c_lo / tpc) * CH, r_hi = min(((c_hi - 1) / tpc + 1) * CH, N);
-        const float* xb = xyz + (size_t)b * N * (size_t)A * 3;   // uniform
-        const uint8_t* mb = amask ? amask + (size_t)b * N * A : nullptr;
-        __syncthreads();                                          // the previous structure's readers are done
-        if ((int)b != staged_b || r_lo != staged_lo || r_hi != staged_hi) {
-            // one residue per thread, its nine loads in flight together (an element per thread made every workgroup walk
-            // 9 N / 512 dependent round trips to L2 per structure: ~10 us of a 170 us launch)
-            float* rb = reinterpret_cast<float*>(k3_rowbuf);
-            for (int row = (int)threadIdx.x; row < r_hi - r_lo; row += (int)blockDim.x) {
-                const float* pr = xb + (size_t)(r_lo + row) * (size_t)A * 3;
-                const float v[9] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[12], pr[13], pr[14]};   // N, CA, CB
+    const unsigned b_first = t0 / n_sub, b_last = (t1 - 1u) / n_sub;
+    for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS) {     // the structures of this workgroup's tasks, KS per staging pass
+        const unsigned ks = min((unsigned)KS, b_last - bs + 1u);
+        __syncthreads();                                          // the previous pass's readers are done
+        // a team of tw waves per structure (all of them when the pass is one structure; one wave each from n_waves structures on)
+        const int tw = max(1, n_waves / (int)ks), n_teams = n_waves / tw;
+        const int team = wave / tw, tl = (wave - team * tw) * 64 + lane, tsz = tw * 64;   // (waves beyond n_teams * tw: no team)
+        for (unsigned s = (unsigned)team; s < ks && team < n_teams; s += (unsigned)n_teams) {
+            char* slot = reinterpret_cast<char*>(k3_rowbuf) + (size_t)s * slot_bytes;
+            uint32_t* rowmask = reinterpret_cast<uint32_t*>(slot + (size_t)max_pairs * 72);
+            float* colpts = reinterpret_cast<float*>(slot + colpts_off);
+            uint8_t* colmask = reinterpret_cast<uint8_t*>(colpts + 9 * Np);
+            uint32_t* colbits = reinterpret_cast<uint32_t*>(colmask);
+            const float* xb = xyz + (size_t)(bs + s) * N * (size_t)A * 3;   // uniform
+            const uint8_t* mb = amask ? amask + (size_t)(bs + s) * N * A : nullptr;
+            // one residue per thread, its loads in flight together (an element per thread made every workgroup walk
+            // 9 N / 512 dependent round trips to L2 per structure: ~10 us of a 170 us launch): rows N, CA, CB; columns CA, O, CB
+            float* rb = reinterpret_cast<float*>(slot);
+            for (int row = tl; row < Np; row += tsz) {
+                const float* pr = xb + (size_t)min(row, N - 1) * (size_t)A * 3;   // (the padding repeats the last residue)
+                const float v[15] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[12], pr[13], pr[14], pr[9], pr[10], pr[11]};
+                if (row < N) {
 #pragma unroll
-                for (int qc = 0; qc < 9; ++qc) rb[(((row >> 1) * 9 + qc) << 1) + (row & 1)] = v[qc];
+                    for (int qc = 0; qc < 9; ++qc) rb[(((row >> 1) * 9 + qc) << 1) + (row & 1)] = v[qc];
+                }
+                colpts[0 * Np + row] = v[3]; colpts[1 * Np + row] = v[4]; colpts[2 * Np + row] = v[5];       // CA
+                colpts[3 * Np + row] = v[9]; colpts[4 * Np + row] = v[10]; colpts[5 * Np + row] = v[11];     // O
+                colpts[6 * Np + row] = v[6]; colpts[7 * Np + row] = v[7]; colpts[8 * Np + row] = v[8];       // CB
             }
-            const int n_pairs = (r_hi - r_lo) / 2 + 1 + (M16 ? 0 : (16 - CH) / 2);   // !M16: up to 16 - CH rows and one beyond the tasks' own (flat mask groups)
-            for (int r = (int)threadIdx.x; r < n_pairs; r += (int)blockDim.x) {
+            const int n_pairs = N / 2 + 1 + (M16 ? 0 : (16 - CH) / 2);   // !M16: up to 16 - CH rows and one beyond the tasks' own (flat mask groups)
+            for (int r = tl; r < n_pairs; r += tsz) {
                 uint32_t w = 0x0707u;
                 if (mb) {
-                    const int ia = min(r_lo + 2 * r, N - 1), ib = min(ia + 1, N - 1);
+                    const int ia = min(2 * r, N - 1), ib = min(ia + 1, N - 1);
                     const uint8_t* pa = mb + (size_t)ia * A;
                     const uint8_t* pb = mb + (size_t)ib * A;
                     w = (pa[0] != 0 ? 1u : 0u) | (pa[1] != 0 ? 2u : 0u) | (pa[4] != 0 ? 4u : 0u) |
@@ -738,16 +749,8 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                 }
                 rowmask[r] = w;
             }
-        }
-        if ((int)b != staged_b) {                                 // the structure's column side: points, masks
-            for (int j = (int)threadIdx.x; j < Np; j += (int)blockDim.x) {
-                const float* pj = xb + (size_t)min(j, N - 1) * (size_t)A * 3;   // (the padding repeats the last residue)
-                const float v[9] = {pj[3], pj[4], pj[5], pj[9], pj[10], pj[11], pj[12], pj[13], pj[14]};   // CA, O, CB
-#pragma unroll
-                for (int qc = 0; qc < 9; ++qc) colpts[qc * Np + j] = v[qc];
-            }
             if constexpr (M16) {
-                for (int j = (int)threadIdx.x; j < N; j += (int)blockDim.x) {
+                for (int j = tl; j < N; j += tsz) {
                     uint8_t a = 1, c2 = 1, o = 1;
                     if (mb) {
                         const uint8_t* mj = mb + (size_t)j * A;
@@ -756,7 +759,7 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                     colmask[j] = a; colmask[N + j] = c2; colmask[2 * N + j] = o;
                 }
             } else {
-                for (int base = wave * 64; base < nw * 32; base += n_waves * 64) {   // (uniform per wave)
+                for (int base = (wave - team * tw) * 64; base < nw * 32; base += tsz) {   // (uniform per wave)
                     const int j = base + lane;
                     bool a = false, c2 = false, o = false;
                     if (j < N) {
@@ -778,21 +781,30 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                 }
             }
         }
-        staged_b = (int)b; staged_lo = r_lo; staged_hi = r_hi;
-        if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
+        const unsigned seg_t0 = max(t0, bs * n_sub), seg_t1 = min(t1, (bs + ks) * n_sub);
+        if (threadIdx.x == 0) next_task = seg_t0 + (unsigned)n_waves;   // the first n_waves tasks are pre-assigned
         __syncthreads();
-        // per plane: the staged rows as one buffer (uniform base, the lane's constant byte offset, the row's byte offset as
-        // a scalar); the flat mask stores address the whole structure
-        const size_t seg = ((size_t)b * N + (size_t)r_lo) * N, sbase = (size_t)b * N * N;
-        auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
-        const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
-                                     r_th = rs(theta + seg), r_ph = rs(phi + seg);
-        const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + (M16 ? seg : sbase)), r_mcb = rs(m_cb + (M16 ? seg : sbase)),
-                                     r_mno = rs(m_no + (M16 ? seg : sbase));
         constexpr int GS = 4 * NC, RS = 64 / GS;                  // M16: 16-column groups of a strip, rows of a store instruction (4 / 8)
         const int gq = lane % GS, rq = lane / GS;                 // ... this lane's group and row
-        int c = c_lo + wave;
-        while (c < c_hi) {
+        unsigned t = seg_t0 + (unsigned)wave;
+        while (t < seg_t1) {
+            // the task's structure (uniform): its slot in LDS, and per plane the structure's rows as one buffer (uniform base, the
+            // lane's constant byte offset, the row's byte offset as a scalar)
+            const unsigned b = t / n_sub;
+            const int c = (int)(t - b * n_sub);
+            const char* slot = reinterpret_cast<const char*>(k3_rowbuf) + (size_t)(b - bs) * slot_bytes;
+            const f32x2* rowbuf = reinterpret_cast<const f32x2*>(slot);
+            const uint32_t* rowmask = reinterpret_cast<const uint32_t*>(slot + (size_t)max_pairs * 72);
+            const float* colpts = reinterpret_cast<const float*>(slot + colpts_off);
+            const uint8_t* colmask = reinterpret_cast<const uint8_t*>(colpts + 9 * Np);
+            const uint32_t* colbits = reinterpret_cast<const uint32_t*>(colmask);
+            constexpr int r_lo = 0;
+            const int r_hi = N;
+            const size_t seg = (size_t)b * N * N, sbase = seg;
+            auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
+            const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
+                                         r_th = rs(theta + seg), r_ph = rs(phi + seg);
+            const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + sbase), r_mcb = rs(m_cb + sbase), r_mno = rs(m_no + sbase);
             const int chunk = c / tpc, strip0 = c - chunk * tpc;
             const int i0 = chunk * CH - r_lo;                     // rows relative to r_lo (CH is even: pairs stay aligned)
             const int i1 = min(i0 + CH, r_hi - r_lo);
@@ -920,9 +932,9 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                 for (int i = i0; i < i1; i += 2) {
                     const int r = i >> 1;
                     const bool two = i + 1 < i1;                  // the last row of an odd N has no partner (uniform)
-                    const f3v nv = {k3_rowbuf[r * 9 + 0], k3_rowbuf[r * 9 + 1], k3_rowbuf[r * 9 + 2]};
-                    const f3v cav = {k3_rowbuf[r * 9 + 3], k3_rowbuf[r * 9 + 4], k3_rowbuf[r * 9 + 5]};
-                    const f3v cbv = {k3_rowbuf[r * 9 + 6], k3_rowbuf[r * 9 + 7], k3_rowbuf[r * 9 + 8]};
+                    const f3v nv = {rowbuf[r * 9 + 0], rowbuf[r * 9 + 1], rowbuf[r * 9 + 2]};
+                    const f3v cav = {rowbuf[r * 9 + 3], rowbuf[r * 9 + 4], rowbuf[r * 9 + 5]};
+                    const f3v cbv = {rowbuf[r * 9 + 6], rowbuf[r * 9 + 7], rowbuf[r * 9 + 8]};
                     const int so = i * row_bytes;
                     // plane by plane, so that only one plane's results are live at a time; each plane's results are pinned
                     // before its store (see k3_sweep)
@@ -985,7 +997,7 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
             }
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
-            c = __builtin_amdgcn_readfirstlane((int)nx);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
     }
 }
@@ -1120,9 +1132,10 @@ inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63)
 // strip idle (N = 64: 143 us against 93 for the one-column kernel at 2^25 pairs; N = 16: 1427 against 282;
 // profiles/r04_k3_shapes.log) -- short chains stay with the one-column kernel.
 constexpr int K3_SWEEP_MIN_N = 100;
-// ... the featuriser's sweep (tasks of two rows, a structure's column points in LDS, two workgroups per CU) pays from 64 on:
-// same-box trace at 2^25 pairs, sweep / one-column kernel: N = 99 314 / 361 us, 80 344 / 365, 64 280 / 300, 48 387 / 354, 33 645 / 474
-constexpr int K3_FEATURISE_MIN_N = 64;
+// ... the featuriser's sweep (tasks of two rows, a structure's column points in LDS, two workgroups per CU, and since round 5
+// several structures per staging pass) pays from 40 on: same-box, 2^25 pairs, min of 20 launches, sweep / one-column kernel:
+// N = 63 276 / 344 us, 56 306 / 352, 48 333 / 371, 40 386 / 417, 33 480 / 449 (profiles/r05_featuriser_shapes.log)
+constexpr int K3_FEATURISE_MIN_N = 40;
 constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
 constexpr int K3_FLAT_UTIL_PERCENT = 78; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
 constexpr int K3_FLAT_UTIL_PERCENT_FAITHFUL = 90;   // (the faithful sweeps, two waves per SIMD, lose more to idle lanes: N = 160 149 us against ~110)
@@ -1332,7 +1345,12 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
     const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
                         std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
     // the per-CU sweep: any N >= K3_FEATURISE_MIN_N whose rows fit in LDS
-    if (!simple && N >= K3_FEATURISE_MIN_N && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
+#ifdef PS_K3_AB
+    static const int feat_min_n = getenv("PS_K3F_MIN_N") ? atoi(getenv("PS_K3F_MIN_N")) : K3_FEATURISE_MIN_N;
+#else
+    constexpr int feat_min_n = K3_FEATURISE_MIN_N;
+#endif
+    if (!simple && N >= feat_min_n && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
         // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
         // columns per lane by the lanes a strip wastes
         const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
@@ -1376,17 +1394,28 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + wgs - 1) / wgs, 4ull);
         const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
         const size_t dyn = two ? K3_LDS_TWO_PER_CU : std::max(need, K3_LDS_ONE_PER_CU);
+        // structures per staging pass (round 5): what the LDS request holds, at most a quarter of a workgroup's share (so that
+        // the workgroups of a CU interleave their passes) -- short chains paid two barriers and a round trip to L2 per structure
+        const size_t slot_bytes = (need + 15) & ~(size_t)15;
+        const unsigned long long n_sub = (unsigned long long)n_chunks * n_strips;
+        const unsigned long long share = (tasks_per_wg + n_sub - 1) / n_sub + 1;
+#ifdef PS_K3_AB
+        static const int ks_max = getenv("PS_K3F_KS_MAX") ? atoi(getenv("PS_K3F_KS_MAX")) : 1 << 20;
+#else
+        constexpr int ks_max = 1 << 20;
+#endif
+        const int KS = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(std::min<unsigned long long>(dyn / slot_bytes, (share + 3) / 4), (unsigned long long)ks_max));
         const unsigned rcpN = (unsigned)((1ull << 32) / (unsigned)N);
         // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves; so do
         // the faithful chains of two columns
         const dim3 block((unsigned)(((NC == 4 || FAITHFUL) ? 512 : 1024) >> (two ? 1 : 0)));
         K3Shape sh;
         sh.nc = NC; sh.vec = vec; sh.skips = !vec; sh.mask_mode = m16 ? 2 : 1; sh.wt = wt; sh.faithful = FAITHFUL; sh.rows_per_task = CH;
-        sh.wgs_per_cu = two ? 2 : 1; sh.structs_per_segment = 1; sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
+        sh.wgs_per_cu = two ? 2 : 1; sh.structs_per_segment = KS; sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
 #define K3F_GO(NC_, VEC_, M16_, WT_)                                                                                              \
     return k3f_go<NC_, VEC_, M16_, WT_, FAITHFUL>(go, exact_sqrt != 0, sh, dim3(grid), block, dyn, xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, \
                                                   phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks, (unsigned)n_tasks,  \
-                                                  tasks_per_wg, rcpN)
+                                                  tasks_per_wg, rcpN, KS, (int)slot_bytes)
         if (wt && NC == 2) K3F_GO(2, true, true, true);
         if (m16 && NC == 2) K3F_GO(2, true, true, false);
         if constexpr (CAN4) {

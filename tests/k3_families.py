@@ -88,7 +88,7 @@ def farm(family, nc=1, vec=0, mask=0, wt=0, faithful=0, wgs=0):
 
 # (B, N, float plane misalignment in bytes, mask plane misalignment, exact_angles, expected arm, run on the GPU)
 FEATURISER_SHAPES = [
-    (3, 48, 0, 0, 0, farm("one_column"), True),
+    (3, 39, 0, 0, 0, farm("one_column"), True),
     (2, 256, 0, 0, 2, farm("one_column"), True),
     (1, 2200, 0, 0, 0, farm("one_column"), True),                                   # rows + column points + masks beyond the LDS
     (2, 512, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=2, wt=1, wgs=1), True),   # BASELINE config 3's layout
@@ -110,7 +110,7 @@ FEATURISER_SHAPES = [
     (1024, 256, 16, 16, 0, farm("featurise", nc=4, vec=1, mask=2, wt=0, wgs=2), True),
     (1024, 256, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=2, wt=1, wgs=2), True),
     # ---- the reference's order of operations: two columns per lane ----
-    (3, 48, 0, 0, 1, farm("one_column", faithful=1), True),
+    (3, 39, 0, 0, 1, farm("one_column", faithful=1), True),
     (2, 256, 0, 0, 3, farm("one_column", faithful=1), True),
     (2, 512, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=1), True),
     (2, 496, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=1), True),
