@@ -466,6 +466,15 @@ _Pragma("unroll")                                                               
                 }                                                                                                        \
             }                                                                                                            \
     }
+#ifdef PS_K3_AB
+// tools only (-DPS_K3_AB): per wave of the last k3_sweep launch, the 100 MHz wall clock at entry, after the first staging
+// barrier, after the wave's first task, after its last task (tools/k3_stamps.py; DESIGN.md section 4, "where K3's time goes")
+__device__ unsigned long long k3_stamps[512 * 16 * 4];
+#define K3_STAMP(slot) if (lane == 0 && blockIdx.x < 512) k3_stamps[((size_t)blockIdx.x * 16 + wave) * 4 + (slot)] = wall_clock64()
+#else
+#define K3_STAMP(slot)
+#endif
+
 template <int NP, int SRC, int NC, bool VEC, bool FAITHFUL = false>
 __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                  AtomSel sel, int row_begin, int row_end, int out_rows,
@@ -481,6 +490,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int n_waves = (int)(blockDim.x >> 6);
     const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
+    K3_STAMP(0);
     if (t0 >= t1) return;                         // whole workgroup
     int amap[NPIq];
     {
@@ -530,6 +540,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
         }
         if (threadIdx.x == 0) next_task = (unsigned)(c_lo + n_waves);   // the first n_waves tasks are pre-assigned
         __syncthreads();
+        K3_STAMP(1);
         // the segment's rows as one buffer: uniform base, the lane's constant byte offset, the row's byte offset as a scalar
         float* obase = out + ((size_t)b * out_rows + (size_t)(r_lo - out_row_origin)) * N;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0xFFFFFFFFu, 0x00020000u);
@@ -564,10 +575,14 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
                 else if (NC == 4 && ncl == 2) K3_SWEEP_ROWS((NC == 4 ? 2 : 1))
                 else K3_SWEEP_ROWS(1)
             }
+#ifdef PS_K3_AB
+            if (c == c_lo + wave) { K3_STAMP(2); }
+#endif
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
             c = __builtin_amdgcn_readfirstlane((int)nx);
         }
+        K3_STAMP(3);
     }
 }
 
@@ -682,7 +697,7 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, int KS, int slot_bytes) {
+    int A, int CH, int n_strips, int n_chunks, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, int KS, int slot_bytes, int pull) {
     static_assert(NC == 2 || NC == 4, "columns per lane");
     static_assert(!M16 || VEC, "16-byte strip mask stores ride on the vector kernels");
     constexpr int POL = WT ? 16 : 0;
@@ -782,11 +797,13 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
             }
         }
         const unsigned seg_t0 = max(t0, bs * n_sub), seg_t1 = min(t1, (bs + ks) * n_sub);
-        if (threadIdx.x == 0) next_task = seg_t0 + (unsigned)n_waves;   // the first n_waves tasks are pre-assigned
+        if (threadIdx.x == 0) next_task = seg_t0 + (unsigned)(n_waves * pull);   // the first n_waves pulls are pre-assigned
         __syncthreads();
         constexpr int GS = 4 * NC, RS = 64 / GS;                  // M16: 16-column groups of a strip, rows of a store instruction (4 / 8)
         const int gq = lane % GS, rq = lane / GS;                 // ... this lane's group and row
-        unsigned t = seg_t0 + (unsigned)wave;
+        // a wave takes `pull` consecutive tasks at a time (1 in the product; round 5 tried 2 and 4 at rows that are not whole 64-byte
+        // segments, so that the segments adjacent tasks share are completed by one wave: NOTES.md)
+        unsigned t = seg_t0 + (unsigned)(wave * pull), t_end = min(t + (unsigned)pull, seg_t1);
         while (t < seg_t1) {
             // the task's structure (uniform): its slot in LDS, and per plane the structure's rows as one buffer (uniform base, the
             // lane's constant byte offset, the row's byte offset as a scalar)
@@ -995,9 +1012,12 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                     else sweep_rows(std::integral_constant<int, 1>{});
                 }
             }
-            unsigned nx = 0;
-            if (lane == 0) nx = atomicAdd(&next_task, 1u);
-            t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+            if (++t >= t_end) {
+                unsigned nx = 0;
+                if (lane == 0) nx = atomicAdd(&next_task, (unsigned)pull);
+                t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+                t_end = min(t + (unsigned)pull, seg_t1);
+            }
         }
     }
 }
@@ -1007,6 +1027,10 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
 // `rows` rows gets about 64 tasks (N = 512: 8 rows per task, 256: 4, 128: 2; with one task per wave a 128-residue segment
 // ended when its slowest wave did: 61 -> 5x us at 2^25 pairs, profiles/r04_k3_shapes.log).  A task costs one LDS atomic.
 inline int k3_rows_per_task(int rows, int min_rows) {
+#ifdef PS_K3_AB
+    static const int forced = getenv("PS_K3_CH") ? atoi(getenv("PS_K3_CH")) : 0;
+    if (forced > 0) return forced;
+#endif
     const int ch = (rows / 64) & ~1;
     return std::min(8, std::max(min_rows, ch));
 }
@@ -1406,6 +1430,11 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
 #endif
         const int KS = (int)std::max<unsigned long long>(1, std::min<unsigned long long>(std::min<unsigned long long>(dyn / slot_bytes, (share + 3) / 4), (unsigned long long)ks_max));
         const unsigned rcpN = (unsigned)((1ull << 32) / (unsigned)N);
+#ifdef PS_K3_AB
+        static const int pull = getenv("PS_K3F_PULL") ? std::max(1, atoi(getenv("PS_K3F_PULL"))) : 1;
+#else
+        constexpr int pull = 1;
+#endif
         // four columns per lane need ~200 VGPRs (three column points x four columns + four interleaved chains): 8 waves; so do
         // the faithful chains of two columns
         const dim3 block((unsigned)(((NC == 4 || FAITHFUL) ? 512 : 1024) >> (two ? 1 : 0)));
@@ -1415,7 +1444,7 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
 #define K3F_GO(NC_, VEC_, M16_, WT_)                                                                                              \
     return k3f_go<NC_, VEC_, M16_, WT_, FAITHFUL>(go, exact_sqrt != 0, sh, dim3(grid), block, dyn, xyz, atom_mask, d_ca, d_cb, d_no, omega, theta, \
                                                   phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, CH, n_strips, n_chunks, (unsigned)n_tasks,  \
-                                                  tasks_per_wg, rcpN, KS, (int)slot_bytes)
+                                                  tasks_per_wg, rcpN, KS, (int)slot_bytes, pull)
         if (wt && NC == 2) K3F_GO(2, true, true, true);
         if (m16 && NC == 2) K3F_GO(2, true, true, false);
         if constexpr (CAN4) {
@@ -1480,3 +1509,11 @@ extern "C" int ps_featuriser_plan_f32(int B, int N, int A, int float_misalign, i
     return k3f_run<false>(nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, A, exact_sqrt, simple,
                           (uintptr_t)float_misalign, (uintptr_t)mask_misalign, go);
 }
+
+#ifdef PS_K3_AB
+// tools only: the stamps of the last k3_sweep launch on the current device (after a synchronise)
+extern "C" int ps_k3_debug_stamps(unsigned long long* host_dst, int n_words) {
+    if (!host_dst || n_words <= 0 || n_words > 512 * 16 * 4) return (int)hipErrorInvalidValue;
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k3_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+#endif

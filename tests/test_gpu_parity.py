@@ -755,7 +755,10 @@ def test_k1_autotune_is_explicit_and_transparent(SB):
         out_d, out_m = torch.empty_like(d0), torch.empty_like(m0)
         res = ops.autotune_pairwise_distance(xg, mg, out_d, out_m)
         assert res is not None and res["rows_per_block"] in (1, 2)
-        assert set(res["ms"]) == {ops._cand_label(c) for c in ops._K1_CANDIDATE_PATTERN} and len(res["ms"]) == 8
+        # every candidate but the one that merely NAMES the default launch at this length (36 KB of idle LDS + 32-residue tiles from
+        # N = 256: timing it against candidate 0 was noise, and a "pick" of it made bench.py re-time the default for nothing)
+        alias = {"rows_per_block": 1, "lds_pad_kb": 36, "jt": 32}
+        assert set(res["ms"]) == {ops._cand_label(c) for c in ops._K1_CANDIDATE_PATTERN if c != alias} and len(res["ms"]) == 7
         assert _lib.get_tuning("k1_rows_per_block") == res["rows_per_block"]
         assert _lib.get_tuning("k1_lds_pad_kb") == res["lds_pad_kb"] and _lib.get_tuning("k1_jt") == res["jt"]
         assert torch.equal(out_d, d0) and torch.equal(out_m, m0)
