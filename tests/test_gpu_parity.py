@@ -1882,6 +1882,53 @@ def test_k5_argument_validation_before_launch(SB):
     assert int(good[1]) == 1 and not good[2:].any() and not torch.equal(xyz, before)
 
 
+def test_k5_back_to_back_launches_draw_consecutive_offsets(SB):
+    """K5's draw counter lives on the device and is advanced by the LAST workgroup of a launch to take its ticket
+    (diffusion.hip: rng_take_ticket / rng_finish), which is only correct if every wave of every workgroup has read
+    (seed, offset) before its workgroup takes a ticket.  Pinned here at a grid of ~23 000 workgroups (90 rounds of the chip):
+    the noise of draw k is extracted by one isolated launch per k (xyz = 0, beta = 1: the update returns eps itself, offset set
+    by hand), then eight back-to-back sampler launches on real coordinates must equal, bit for bit, eight launches with that
+    noise injected -- i.e. launch k drew with offset k in every workgroup, none with k - 1 or k + 1 -- and leave the counter at
+    8 with every ticket word back at zero.  The fused K5 + K4 step draws the same stream."""
+    from protstruc_amd import ops
+    B, N, A, K = 2048, 512, 15, 8
+    g = torch.Generator().manual_seed(5)
+    xyz0 = torch.randn(B, N, A, 3, generator=g).cuda()
+    beta = (torch.rand(B, generator=g) * 0.5 + 0.01).cuda()
+    one = torch.ones(B, device="cuda")
+    sb = SB.from_xyz(torch.zeros(1, 2, A, 3)).manual_seed(2024)
+    state0 = sb._rng_state.clone()
+    eps = []
+    for k in range(K):                                   # draw k in isolation
+        st = state0.clone()
+        st[1] = k
+        z = torch.zeros(B, N, A, 3, device="cuda")
+        ops.diffuse_(z, one, st)
+        torch.cuda.synchronize()
+        assert int(st[1]) == k + 1 and not st[2:].any()
+        eps.append(z)
+    assert not torch.equal(eps[0], eps[1]) and abs(eps[0].mean().item()) < 1e-3 and abs(eps[0].var().item() - 1) < 1e-3
+    a, st = xyz0.clone(), state0.clone()
+    for k in range(K):                                   # back to back: launch k + 1 is queued while launch k runs
+        ops.diffuse_(a, beta, st)
+    b = xyz0.clone()
+    for k in range(K):
+        ops.diffuse_(b, beta, None, eps[k])
+    torch.cuda.synchronize()
+    assert int(st[1]) == K and not st[2:].any(), "draw counter must advance by one per launch, tickets back to 0"
+    assert torch.equal(a, b), "a launch drew with another offset than its own"
+    # the fused step (another kernel, the same ticket protocol read through LDS) draws the same stream
+    Bf = 64
+    c, st = xyz0[:Bf].clone(), state0.clone()
+    for k in range(K):
+        ops.diffuse_frames_(c, beta[:Bf], 0, 1, 2, 1, st)
+    d = xyz0[:Bf].clone()
+    for k in range(K):
+        ops.diffuse_(d, beta[:Bf], None, eps[k][:Bf].contiguous())
+    torch.cuda.synchronize()
+    assert int(st[1]) == K and not st[2:].any() and torch.equal(c, d)
+
+
 def test_k5_graph_capture_replays_fresh_noise(SB):
     B, N = 4, 64
     sb = SB.from_xyz(torch.zeros(B, N, 15, 3)).manual_seed(99)

@@ -1,6 +1,7 @@
 #!/usr/bin/python3
 """Workloads for rocprofv3 (run as `rocprofv3 ... -- python3 tools/profile_workload.py <what> [reps]`):
 
+    k3p     the same as k3, host-paced (a synchronise after every launch)
     k3      BASELINE config 3 (B=128, N_res=512): pairwise_dihedrals (2,2) CA,CB|CA,CB and (3,1) N,CA,CB|CB,
             pairwise_planar_angles (2,1) CA,CB|CB, and the fused inter_residue_geometry -- in both arithmetic modes
     k1a     K1 at atom14 (N=256) and atom37 (N=128), ~8 GB of output each: default dispatch (fixed-A flat pattern
@@ -41,7 +42,12 @@ def repeat(fn):
     torch.cuda.synchronize()
 
 
-if what == "k3":
+if what in ("k3", "k3p"):
+    if what == "k3p":        # host-paced: every launch waits for the previous one (a back-to-back train runs at a sagging clock, and
+        def repeat(fn):      # what follows the featuriser inherits it: profiles/r05_k3_timeline_back_to_back.csv)
+            for _ in range(2 + reps):
+                fn()
+                torch.cuda.synchronize()
     xyz, mask = synth(128, 512)
     sb = StructureBatch.from_xyz(xyz, mask)
     for faithful in (False, True):      # the fast arithmetic, then the reference's order of operations (kernel names differ: FAITHFUL)

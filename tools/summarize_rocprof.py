@@ -120,7 +120,7 @@ def ranges(d, out, bench_json, prefix="k1_"):
         sel = rows[a:b]
         ms = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in sel]
         res[name] = {"dispatch_ordinals": [a, b], "kernels": sorted({short(r["Kernel_Name"]) for r in sel}),
-                     "grids": sorted({int(r["Grid_Size"]) for r in sel}),
+                     "grids": sorted({"x".join(r[k] for k in sorted(r) if k.startswith("Grid_Size")) for r in sel}),
                      "mean_ms": sum(ms) / len(ms) if ms else None, "min_ms": min(ms) if ms else None, "max_ms": max(ms) if ms else None,
                      "frac_of_hbm_peak_at_the_trace_mean": (roof["algorithmic_bytes_per_launch"] / (sum(ms) / len(ms) * 1e-3) / 8e12) if ms else None}
     res["timed_region"]["bench_line_kernel_ms_hip_events"] = roof["kernel_ms"]
