@@ -569,7 +569,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
             } else {
                 // (not three of four, and nothing for the (2,2) dihedral at four columns: with those variants that instantiation
                 // spilled 3-5 registers)
-                constexpr bool SKIP = FAITHFUL || !(NP == 4 && SRC == 12 && NC == 4);   // (the faithful kernels have 256 VGPRs)
+                constexpr bool SKIP = true;
                 const int ncl = SKIP ? min(NC, (N - strip * 64 * NC + 63) >> 6) : NC;   // live column groups of this strip (uniform)
                 if (!SKIP || ncl == NC || ncl == 3) K3_SWEEP_ROWS(NC)
                 else if (NC == 4 && ncl == 2) K3_SWEEP_ROWS((NC == 4 ? 2 : 1))
@@ -1095,7 +1095,7 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
     char name[96];
     snprintf(name, sizeof name, "k3_sweep<NP=%d,SRC=%d,NC=%d,VEC=%d,FAITHFUL=%d>", NP, SRC, NC, (int)VEC, (int)FAITHFUL);
     K3Shape sh;
-    sh.nc = NC; sh.vec = VEC; sh.skips = !VEC && !(NP == 4 && SRC == 12 && NC == 4 && !FAITHFUL); sh.faithful = FAITHFUL; sh.rows_per_task = CH;
+    sh.nc = NC; sh.vec = VEC; sh.skips = !VEC; sh.faithful = FAITHFUL; sh.rows_per_task = CH;
     sh.wgs_per_cu = two ? 2 : 1; sh.structs_per_segment = 1; sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
     return k3_go(go, "sweep", name, sh, k3_sweep<NP, SRC, NC, VEC, FAITHFUL>, &prepared, dim3(grid), dim3(THREADS >> (two ? 1 : 0)), dyn, 4u,
                  xyz, out, N, A, sel, row_begin, row_end, out_rows, out_row_origin, CH, n_strips, n_chunks, (unsigned)n_tasks, tasks_per_wg);
@@ -1207,10 +1207,12 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const bool fits = !simple && N >= K3_SWEEP_MIN_N && (size_t)((rows + 2) / 2) * (NPI > 0 ? NPI : 1) * 3 * 8 <= K3_LDS_MAX &&
                       (unsigned long long)rows * (unsigned long long)N * 4ull < (1ull << 31);
     // four columns per lane only where the instantiation keeps its registers (three or two column-side points of a
-    // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers; the faithful
-    // kernels' 512-thread workgroups have 256 and take four columns for every split)
+    // dihedral times four columns do not fit the 128 VGPRs of a 1024-thread workgroup: 4-95 spilled registers -- the (2,2)
+    // split fitted with 124 until round 5's three-instruction dot products pushed it to 128 + 9 spilled; at two columns it
+    // runs as fast (same-box A/B 54.8 / 52.5 against 54.0 / 52.0 us, profiles/r05_k3_modes_first.log) and skips dead groups;
+    // the faithful kernels' 512-thread workgroups have 256 and take four columns for every split)
     constexpr bool NC4 = FAITHFUL ? K3_FAITHFUL_NC4(NP, SRC)
-                                  : (NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 12 || SRC == 15);
+                                  : (NP == 3 || SRC == 0 || SRC == 1 || SRC == 2 || SRC == 4 || SRC == 8 || SRC == 15);
 #ifdef PS_K3_AB
     static const int force_nc = getenv("PS_K3_NC") ? atoi(getenv("PS_K3_NC")) : 0;
     const bool allow4 = force_nc != 2;
@@ -1226,7 +1228,7 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     // The 64-apart layout skips the dead column groups of a row's last strip: it computes ceil(N / 64) groups per row pair
     // where the vector layouts compute whole strips -- taken also for even N where that saves more than its dword stores cost
     const long long gn = (N + 63) / 64, gv = (NC4 && ok4 && (!ok2 || w4 <= w2) ? w4 : w2) / 64;
-    constexpr bool SKIPS = FAITHFUL || !(NP == 4 && SRC == 12);   // (the fast (2,2) dihedral's four-column instantiation evaluates every group: registers)
+    constexpr bool SKIPS = true;   // (every instantiation skips dead groups since the fast (2,2) dihedral takes two columns per lane: round 5)
     // the sweep layout this launch would take: vector stores or columns 64 apart, columns per lane, and the 64-column groups
     // it evaluates per row pair (dead ones included unless skipped)
     const bool vec = (ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100);

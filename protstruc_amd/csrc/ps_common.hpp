@@ -251,6 +251,16 @@ __device__ __forceinline__ float angle3_ref(f3 a, f3 b, f3 c) {
     return acos_lib(cosine);               // no clamp, as geometry.py:64-71
 }
 
+// Dot product of the FAST pairwise forms (round 5): fma(a.z, b.z, fma(a.y, b.y, fma(a.x, b.x, +0))) -- three instructions
+// instead of five (K3's time is the vector unit's).  The first fma keeps dot3's `0 +`: a sum of -0 terms is still +0, which is
+// what makes the (i == j) diagonal of pairwise_dihedrals exactly +0.0; a sum of exact zeros stays an exact zero.  Elsewhere
+// it differs from the reference's products-then-adds by rounding only (one rounding instead of three: closer to the
+// real dot product).  The cross products keep their unfused form: a * b - a * b has to cancel exactly on the diagonal.  The
+// faithful forms (dihedral4_ref, angle3_ref) do not use it.
+__device__ __forceinline__ float dot3_fast(f3 a, f3 b) {
+    return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, __builtin_fmaf(a.x, b.x, 0.0f)));
+}
+
 // atan2 of the PAIRWISE kernels (K3 and the fused featuriser; K2 and the pointwise entry keep atan2_ps with every IEEE
 // special case).  Same polynomial, same quadrant logic, same signed-zero behaviour (atan2(+0, +0) = +0, atan2(+0, -0) =
 // pi); what is dropped are six per-element compare / select instructions that only matter for infinite arguments:
@@ -282,17 +292,16 @@ __device__ __forceinline__ float atan2_k3(float y, float x) {
     return copysignf(r, y);
 }
 
-// dihedral4 with atan2_k3 and without the leading `0 +` of the one dot product whose terms are squares (b1 . b1: its
-// terms are never -0, so the sum is the same bits)
+// dihedral4 with atan2_k3 and the three-instruction dot products (dot3_fast)
 __device__ __forceinline__ float dihedral4_k3(f3 a, f3 b, f3 c, f3 d) {
     f3 b0 = sub3(a, b);
     f3 b1 = sub3(c, b);
     f3 b2n = sub3(c, d);
     f3 n1 = cross3(b0, b1);
     f3 n2 = cross3(b1, b2n);
-    const float nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
-    float x = dot3(n1, n2) * __builtin_amdgcn_rsqf(nn);
-    float y = dot3(n1, b2n);
+    const float nn = dot3_fast(b1, b1);
+    float x = dot3_fast(n1, n2) * __builtin_amdgcn_rsqf(nn);
+    float y = dot3_fast(n1, b2n);
     return atan2_k3(y, x);
 }
 
@@ -317,6 +326,10 @@ __device__ __forceinline__ f3v cross3v(f3v u, f3v v) {
     r.y = u.z * v.x - u.x * v.z;
     r.z = u.x * v.y - u.y * v.x;
     return r;
+}
+// dot3_fast on both halves
+__device__ __forceinline__ f32x2 dot3v_fast(f3v a, f3v b) {
+    return __builtin_elementwise_fma(a.z, b.z, __builtin_elementwise_fma(a.y, b.y, __builtin_elementwise_fma(a.x, b.x, f32x2{0.0f, 0.0f})));
 }
 // atan2_ps on both halves: the polynomial, the squares and the quadrant subtractions as packed mul / fma / add
 // (v_pk_*_f32 issue at the scalar rate, so every packed instruction retires two elements' worth); abs / min / max /
@@ -393,9 +406,9 @@ __device__ __forceinline__ f32x2 atan2_k3_v(f32x2 y, f32x2 x) {
 __device__ __forceinline__ f32x2 dihedral4v_k3(f3v a, f3v b, f3v c, f3v d) {
     const f3v b0 = sub3v(a, b), b1 = sub3v(c, b), b2n = sub3v(c, d);
     const f3v n1 = cross3v(b0, b1), n2 = cross3v(b1, b2n);
-    const f32x2 nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
-    const f32x2 x = dot3v(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
-    const f32x2 y = dot3v(n1, b2n);
+    const f32x2 nn = dot3v_fast(b1, b1);
+    const f32x2 x = dot3v_fast(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+    const f32x2 y = dot3v_fast(n1, b2n);
     return atan2_k3_v(y, x);
 }
 
@@ -453,6 +466,7 @@ __device__ __forceinline__ void atan2_k3_vn(const f32x2 (&y)[NC], const f32x2 (&
 
 // dot3v with the leading `0 +` folded into the first product: fma(a, b, +0) rounds a * b once and adds +0, which is
 // bit for bit (0 + a * b) -- including the -0 -> +0 case the `0 +` exists for -- in one instruction instead of two.
+// (The faithful forms' dot product: products first, then adds, as the reference.)
 __device__ __forceinline__ f32x2 dot3v_f(f3v a, f3v b) {
     const f32x2 px = __builtin_elementwise_fma(a.x, b.x, f32x2{0.0f, 0.0f}), py = a.y * b.y, pz = a.z * b.z;
     return (px + py) + pz;
@@ -467,9 +481,9 @@ __device__ __forceinline__ void dihedral4v_k3_n(const f3v (&a)[NC], const f3v (&
     for (int q = 0; q < NC; ++q) {
         const f3v b0 = sub3v(a[q], b[q]), b1 = sub3v(c[q], b[q]), b2n = sub3v(c[q], d[q]);
         const f3v n1 = cross3v(b0, b1), n2 = cross3v(b1, b2n);
-        const f32x2 nn = (b1.x * b1.x + b1.y * b1.y) + b1.z * b1.z;
-        x[q] = dot3v_f(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
-        y[q] = dot3v_f(n1, b2n);
+        const f32x2 nn = dot3v_fast(b1, b1);
+        x[q] = dot3v_fast(n1, n2) * f32x2{__builtin_amdgcn_rsqf(nn.x), __builtin_amdgcn_rsqf(nn.y)};
+        y[q] = dot3v_fast(n1, b2n);
     }
     atan2_k3_vn<NC>(y, x, out);
 }
@@ -556,8 +570,8 @@ __device__ __forceinline__ f32x2 dist3v_t(f3v a, f3v b) {
 
 __device__ __forceinline__ f32x2 angle3v(f3v a, f3v b, f3v c) {
     const f3v ba = sub3v(a, b), bc = sub3v(c, b);
-    const f32x2 num = dot3v(ba, bc);
-    const f32x2 na = dot3v(ba, ba), nb = dot3v(bc, bc);
+    const f32x2 num = dot3v_fast(ba, bc);
+    const f32x2 na = dot3v_fast(ba, ba), nb = dot3v_fast(bc, bc);
     return acos_ps_v((num * f32x2{__builtin_amdgcn_rsqf(na.x), __builtin_amdgcn_rsqf(na.y)}) * f32x2{__builtin_amdgcn_rsqf(nb.x), __builtin_amdgcn_rsqf(nb.y)});
 }
 
@@ -567,9 +581,8 @@ __device__ __forceinline__ void angle3v_n(const f3v (&a)[NC], const f3v (&b)[NC]
 #pragma unroll
     for (int q = 0; q < NC; ++q) {
         const f3v ba = sub3v(a[q], b[q]), bc = sub3v(c[q], b[q]);
-        const f32x2 num = dot3v_f(ba, bc);
-        // squares are never -0, so the sums need no leading `0 +` (same bits as dot3v(ba, ba), dot3v(bc, bc))
-        const f32x2 na = (ba.x * ba.x + ba.y * ba.y) + ba.z * ba.z, nb = (bc.x * bc.x + bc.y * bc.y) + bc.z * bc.z;
+        const f32x2 num = dot3v_fast(ba, bc);
+        const f32x2 na = dot3v_fast(ba, ba), nb = dot3v_fast(bc, bc);
         cs[q] = (num * f32x2{__builtin_amdgcn_rsqf(na.x), __builtin_amdgcn_rsqf(na.y)}) * f32x2{__builtin_amdgcn_rsqf(nb.x), __builtin_amdgcn_rsqf(nb.y)};
     }
     acos_ps_vn<NC>(cs, out);
@@ -578,7 +591,7 @@ __device__ __forceinline__ void angle3v_n(const f3v (&a)[NC], const f3v (&b)[NC]
 __device__ __forceinline__ float angle3(f3 a, f3 b, f3 c) {
     f3 ba = sub3(a, b);
     f3 bc = sub3(c, b);
-    return acos_ps((dot3(ba, bc) * __builtin_amdgcn_rsqf(dot3(ba, ba))) * __builtin_amdgcn_rsqf(dot3(bc, bc)));
+    return acos_ps((dot3_fast(ba, bc) * __builtin_amdgcn_rsqf(dot3_fast(ba, ba))) * __builtin_amdgcn_rsqf(dot3_fast(bc, bc)));
 }
 
 // ---- the FAITHFUL forms for NC columns x two rows (round 5): dihedral4_ref / angle3_ref bit for bit, packed ----

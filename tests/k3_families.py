@@ -12,7 +12,7 @@ An arm = (family, columns_per_lane, vector_stores, skips_dead_groups, faithful, 
 
 CA_CB__CA_CB = (4, [1, 4], [1, 4])       # (2,2) dihedral, SRC = 12
 N_CA_CB__CB = (4, [0, 1, 4], [4])        # (3,1) dihedral, SRC = 8
-C__N_CA_C = (4, [2], [0, 1, 2])          # (1,3) dihedral, SRC = 14: two columns per lane in the fast arithmetic (registers)
+C__N_CA_C = (4, [2], [0, 1, 2])          # (1,3) dihedral, SRC = 14: two columns per lane in the fast arithmetic (registers), like (2,2)
 CA_CB__CB = (3, [1, 4], [4])             # (2,1) planar angle
 ALL_I = (4, [0, 1, 2, 3], [])            # every point from the row residue (SRC = 0)
 
@@ -34,7 +34,7 @@ K3_SHAPES = [
     (700, 48, N_CA_CB__CB, None, False, 4, 0, arm("flat", nc=4, skips=1, wgs=2), True),
     (5, 33, C__N_CA_C, (4, 31), True, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
     (2, 140, CA_CB__CB, None, False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),            # three column groups for 140 columns: flat
-    (2, 160, CA_CB__CA_CB, (1, 160), False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),     # the (2,2) dihedral evaluates four
+    (2, 130, CA_CB__CA_CB, (1, 130), False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
     (2, 99, CA_CB__CB, (1, 98), False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
     (700, 65, N_CA_CB__CB, None, False, 4, 0, arm("flat", nc=4, skips=1, wgs=2), True),
     (5, 80, C__N_CA_C, (4, 77), True, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
@@ -42,14 +42,15 @@ K3_SHAPES = [
     (2, 256, N_CA_CB__CB, None, False, 0, 2, arm("one_column"), True),                       # the diagnostic bit
     (1, 50000, CA_CB__CB, (0, 13000), True, 0, 0, arm("one_column"), False),                 # 32-bit store offsets would overflow
     (1, 14000, N_CA_CB__CB, None, False, 0, 0, arm("one_column"), False),                    # the rows do not fit the LDS
-    (2, 512, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=1), True),       # BASELINE config 3's layout
+    (2, 512, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=1, wgs=1), True),       # BASELINE config 3's layout, (2,2) split
+    (2, 512, N_CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=1), True),        # ... the (3,1) split
     (2, 256, CA_CB__CB, (10, 200), True, 0, 0, arm("sweep", nc=4, vec=1, wgs=1), True),
     (2, 512, C__N_CA_C, None, False, 0, 0, arm("sweep", nc=2, vec=1, wgs=1), True),
-    (2, 302, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=1, wgs=1), True),       # N % 4 != 0
+    (2, 254, N_CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=1, wgs=1), True),        # N % 4 != 0
     (2, 256, CA_CB__CA_CB, None, False, 8, 0, arm("sweep", nc=2, vec=1, wgs=1), True),       # an 8-byte aligned output
     (2, 301, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),
     (2, 301, N_CA_CB__CB, (7, 290), False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),
-    (2, 511, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=0, wgs=1), True),   # the (2,2) dihedral at four columns: no skipping
+    (2, 511, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
     (2, 301, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
     (3, 101, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
     (2, 256, CA_CB__CB, None, False, 4, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),  # a 4-byte misaligned output
@@ -58,7 +59,7 @@ K3_SHAPES = [
     (2048, 101, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=2), True),
     (2, 512, ALL_I, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=1), True),
     (2048, 256, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=2), True),
-    (2048, 255, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=0, wgs=2), True),
+    (2048, 255, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=2), True),
     (2048, 255, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=2), True),
     # ---- the reference's order of operations (bit 0 of exact_angles) ----
     (3, 16, CA_CB__CA_CB, None, False, 0, 1, arm("small", nc=16, faithful=1), True),

@@ -76,8 +76,9 @@ def test_plan_baseline_config3():
     """BASELINE config 3 (B=128, N=512): the three features and the featuriser, both arithmetic modes."""
     for mode, faithful in ((0, 0), (1, 1)):
         p = _lib.k3_plan(128, 512, 15, [1, 4], [1, 4], 4, exact_angles=mode, cu_count=256)
-        assert p["kernel"] == f"k3_sweep<NP=4,SRC=12,NC=4,VEC=1,FAITHFUL={faithful}>" and p["n_workgroups"] == 256
-        assert p["n_tasks"] == 128 * 2 * 64 and p["tasks_per_workgroup"] == 64 and p["rows_per_task"] == 8
+        nc = 4 if faithful else 2        # (the fast (2,2) split keeps its registers at two columns per lane)
+        assert p["kernel"] == f"k3_sweep<NP=4,SRC=12,NC={nc},VEC=1,FAITHFUL={faithful}>" and p["n_workgroups"] == 256
+        assert p["n_tasks"] == 128 * (512 // (64 * nc)) * 64 and p["tasks_per_workgroup"] == p["n_tasks"] // 256 and p["rows_per_task"] == 8
         p = _lib.k3_plan(128, 512, 15, [0, 1, 4], [4], 4, exact_angles=mode, cu_count=256)
         assert p["kernel"] == f"k3_sweep<NP=4,SRC=8,NC=4,VEC=1,FAITHFUL={faithful}>"
         p = _lib.k3_plan(128, 512, 15, [1, 4], [4], 3, exact_angles=mode, cu_count=256)
