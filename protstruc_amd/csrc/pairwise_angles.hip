@@ -1,21 +1,27 @@
-// K3 -- inter-residue dihedrals and planar angles over all residue pairs.
+// K3 -- inter-residue dihedrals and planar angles over all residue pairs, and the fused featuriser.
 // Replaces StructureBatch.pairwise_dihedrals / pairwise_planar_angles and the
 // (B, N*N, n_i+n_j, 3) gather of _pairwise_xyz (reference protstruc.py:589-660);
 // geometry.dihedral / geometry.angle (geometry.py:39-124) are evaluated per pair
 // in registers, so the 1.6 GB gather of the reference is never materialised.
 //
-// Layout of the sweep: a workgroup owns 256 column residues j (one per lane) and
-// IR row residues i of one structure.  The (up to four) points taken from residue
-// j are loaded once into registers; the points taken from residue i have a
-// wave-uniform address, so the compiler fetches them with scalar loads and they
-// ride in SGPRs.  Which point comes from which side is a template parameter
-// (SRC bit k = 1: point k from j), so all j-only sub-expressions (e.g. d - c for
-// the (2,2) split) are loop-invariant and hoisted out of the i loop, and nothing
-// is selected at run time.  Each store instruction writes 64 consecutive floats
-// of one output row.  4 bytes are written per pair against ~90 flops and an
-// atan2 / acos: the kernel is VALU-bound, not HBM-bound; its
-// arithmetic (triple-product dihedral, polynomial atan2 / acos: ps_common.hpp)
-// is where the 1e-5 parity tolerance is spent.
+// Which point comes from which side is a template parameter (SRC bit k = 1: point k
+// from the column residue j), so nothing is selected at run time and what depends on
+// one side only is shared or hoisted.  4 bytes are written per pair against ~90 flops
+// and an atan2 / acos: the kernels are bound by the vector unit, not by HBM.
+// Two arithmetics (exact_angles bit 0, ps_common.hpp): the fast one spends the 1e-5
+// parity tolerance (triple-product dihedral, polynomial atan2 / acos), the faithful one
+// is the reference's order of operations; every kernel below exists in both.
+//
+// Kernels, in the order of this file (DESIGN.md section 4 has the dispatch table and
+// the numbers; ps_k3_plan_f32 / ps_featuriser_plan_f32 name the one a launch takes):
+//   k3_pairwise_angles   one column per lane, rows by scalar loads: the layout-free twin
+//                        every other kernel is held to bit for bit, and the fallback
+//   k3_small             N <= 32: one wave per structure
+//   k3_flat              33..99 residues (and wherever a sweep would idle its lanes): flat
+//                        over (row pair, column), several structures staged per pass
+//   k3_sweep             >= 100 residues: one workgroup per CU, rows staged in LDS, tasks
+//                        pulled from an LDS counter, NC column residues per lane
+//   k3_inter_residue_geometry, k3_featurise   the fused featuriser: one-column / sweep
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
@@ -567,8 +573,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
             if constexpr (VEC) {
                 K3_SWEEP_ROWS(NC)
             } else {
-                // (not three of four, and nothing for the (2,2) dihedral at four columns: with those variants that instantiation
-                // spilled 3-5 registers)
+                // (not three of four: that variant spilled 3-5 registers in some instantiations)
                 constexpr bool SKIP = true;
                 const int ncl = SKIP ? min(NC, (N - strip * 64 * NC + 63) >> 6) : NC;   // live column groups of this strip (uniform)
                 if (!SKIP || ncl == NC || ncl == 3) K3_SWEEP_ROWS(NC)
@@ -1154,7 +1159,7 @@ inline int k3_one_column_threads(int N) { return N >= 256 ? 256 : 64 * ((N + 63)
 // The per-CU sweep kernels pay two workgroup barriers and a staging pass per (structure, strip) segment and give a wave a
 // strip of 64 * NC columns: below ~100 residues a segment has fewer tasks than the workgroup has waves and most lanes of a
 // strip idle (N = 64: 143 us against 93 for the one-column kernel at 2^25 pairs; N = 16: 1427 against 282;
-// profiles/r04_k3_shapes.log) -- short chains stay with the one-column kernel.
+// profiles/r04_k3_shapes.log) -- shorter chains take k3_flat (round 5; the one-column kernel before).
 constexpr int K3_SWEEP_MIN_N = 100;
 // ... the featuriser's sweep (tasks of two rows, a structure's column points in LDS, two workgroups per CU, and since round 5
 // several structures per staging pass) pays from 40 on: same-box, 2^25 pairs, min of 20 launches, sweep / one-column kernel:
