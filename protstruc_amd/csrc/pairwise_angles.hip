@@ -241,11 +241,13 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
 //     element's offset lies beyond the buffer descriptor's range and the hardware drops it), so the NC chains stay in one
 //     basic block and interleave.
 // Same arithmetic per pair as the one-column kernel: same bits.
-template <int NP, int SRC, int NC, bool FAITHFUL, bool ROWMAJOR>
+template <int NP, int SRC, int NC, bool FAITHFUL, int MAP>
 __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                 AtomSel sel, int row_begin, int row_end, int out_rows,
                                                 int out_row_origin, int KS, unsigned tps, unsigned n_tasks,
-                                                unsigned tasks_per_wg, unsigned rcpN, int col_vec4, int slot_vec4) {
+                                                unsigned tasks_per_wg, unsigned rcpN, int col_vec4, int slot_vec4,
+                                                unsigned rcpTC, int vec2) {
+    constexpr bool ROWMAJOR = MAP == 1;
     static_assert(NC == 2 || NC == 4, "elements per lane");
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     constexpr int NPIq = NPI > 0 ? NPI : 1, NPJq = NPJ > 0 ? NPJ : 1;
@@ -306,6 +308,71 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
             const k3_f32x4* rowp = slot + col_vec4;
             float* obase = out + ((size_t)b * out_rows + (size_t)(row_begin - out_row_origin)) * N;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, rows * N * 4, 0x00020000u);   // this structure's rows, exactly
+            if constexpr (MAP == 2) {
+                // TILE map: a lane's element is a 2 x 2 tile -- two row pairs x two adjacent columns, four chains -- so that what
+                // depends on the row pair alone is shared by the tile's two columns and what depends on the column alone by its two
+                // row pairs (as in the sweep), the index arithmetic is paid once per tile, and two adjacent columns are one 8-byte store
+                const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
+                const unsigned ti = chunk * 64u + (unsigned)lane;
+                const bool lt = ti < FT;
+                const unsigned tcl = min(ti, FT - 1u);
+                unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
+                if (tc >= TC) ++tr, tc -= TC;
+                const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
+                const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
+                const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
+                f3v P[NP][4];
+                {
+                    int qi = 0, qj = 0;
+#pragma unroll
+                    for (int k = 0; k < NP; ++k) {
+                        if ((SRC >> k) & 1) {
+                            const k3_f32x4 p0 = slot[qj * N + c0], p1 = slot[qj * N + c1];
+                            P[k][0] = P[k][2] = mk3v(f3{p0.x, p0.y, p0.z}, f3{p0.x, p0.y, p0.z});
+                            P[k][1] = P[k][3] = mk3v(f3{p1.x, p1.y, p1.z}, f3{p1.x, p1.y, p1.z});
+                            ++qj;
+                        } else {
+                            const k3_f32x4 xa = rowp[(rpA * NPI + qi) * 2], xb = rowp[(rpB * NPI + qi) * 2];
+                            const f32x2 za = *reinterpret_cast<const f32x2*>(rowp + (rpA * NPI + qi) * 2 + 1);
+                            const f32x2 zb = *reinterpret_cast<const f32x2*>(rowp + (rpB * NPI + qi) * 2 + 1);
+                            P[k][0] = P[k][1] = f3v{f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, za};
+                            P[k][2] = P[k][3] = f3v{f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}, zb};
+                            ++qi;
+                        }
+                    }
+                }
+                f32x2 v[4];
+                if constexpr (NP == 4 && FAITHFUL)
+                    dihedral4v_ref_n<4>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (NP == 4)
+                    dihedral4v_k3_n<4>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (FAITHFUL)
+                    angle3v_ref_n<4>(P[0], P[1], P[2], v);
+                else
+                    angle3v_n<4>(P[0], P[1], P[2], v);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
+                const int offA = (int)__umul24((unsigned)(2 * rpA), (unsigned)N) * 4 + c0 * 4;
+                const int offB = (int)__umul24((unsigned)(2 * rpB), (unsigned)N) * 4 + c0 * 4;
+                const bool rA1 = 2 * rpA + 1 < rows, rB0 = lrB, rB1 = lrB && 2 * rpB + 1 < rows;   // rows 2 rpA + 1, 2 rpB, 2 rpB + 1 exist
+                constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
+                if (vec2) {      // (uniform) N even and the rows 8-byte aligned: the tile's two columns are one store
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lt ? offA : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].y, v[3].y}), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
+                } else {
+                    const bool l1 = lt && lc1;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].x), rsrc, lt ? offA : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].x), rsrc, l1 ? offA + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].y), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].y), rsrc, (l1 && rA1) ? offA + N * 4 + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].x), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].x), rsrc, (l1 && rB0) ? offB + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].y), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].y), rsrc, (l1 && rB1) ? offB + N * 4 + 4 : DEAD, 0, 0);
+                }
+            } else {
             // ROWMAJOR (N <= 64): the lane is column `lane` and its NC elements are NC consecutive row pairs -- no per-lane index
             // arithmetic at all, the row side is one uniform address per element and what depends on the column alone is
             // shared by the NC chains.  Otherwise: NC elements 64 apart in the flat index
@@ -377,6 +444,7 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
             else if (NC == 4 && ngr == 3u) run(std::integral_constant<int, NC == 4 ? 3 : 1>{});
             else if (NC == 4 && ngr == 2u) run(std::integral_constant<int, NC == 4 ? 2 : 1>{});
             else run(std::integral_constant<int, 1>{});
+            }
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
             t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
@@ -1109,14 +1177,16 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
 // LDS the flat kernel stages its structures in (one workgroup per CU: the request keeps a second one off the CU)
 constexpr size_t K3_FLAT_LDS = 128 * 1024;
 
-template <int NP, int SRC, int NC, bool FAITHFUL, bool ROWMAJOR>
+template <int NP, int SRC, int NC, bool FAITHFUL, int MAP>
 int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end, int out_rows,
-                int out_row_origin, const K3Go& go) {
+                int out_row_origin, unsigned out_misalign_bytes, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     const int rows = row_end - row_begin, rp = (rows + 1) / 2;
     const unsigned long long F = (unsigned long long)rp * N;
     // tasks per structure: NC elements per lane -- 64 apart in the flat index, or (ROWMAJOR) NC row pairs of the lane's column
-    const unsigned tps = ROWMAJOR ? (unsigned)((rp + NC - 1) / NC) : (unsigned)((F + 64 * NC - 1) / (64 * NC));
+    constexpr bool ROWMAJOR = MAP == 1;
+    const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(rp + 1) / 2;      // MAP == 2: tiles of two row pairs x two columns
+    const unsigned tps = MAP == 2 ? (TR * TC + 63u) / 64u : ROWMAJOR ? (unsigned)((rp + NC - 1) / NC) : (unsigned)((F + 64 * NC - 1) / (64 * NC));
     const unsigned long long n_tasks = (unsigned long long)tps * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int col_vec4 = NPJ * N, slot_vec4 = col_vec4 + rp * NPI * 2;   // 16-byte units: {x, y, z, -} per column atom; two per row-pair atom
@@ -1140,13 +1210,16 @@ int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel
     const size_t dyn = wgs == 2 ? K3_LDS_TWO_PER_CU : std::max((size_t)KS * slot_vec4 * 16, K3_LDS_ONE_PER_CU);
     static unsigned long long prepared[1] = {0};
     char name[96];
-    snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,NC=%d,FAITHFUL=%d,ROWMAJOR=%d>", NP, SRC, NC, (int)FAITHFUL, (int)ROWMAJOR);
+    snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,NC=%d,FAITHFUL=%d,MAP=%d>", NP, SRC, NC, (int)FAITHFUL, MAP);
+    // MAP == 2: two adjacent columns as one 8-byte store where the rows allow it
+    const int vec2 = MAP == 2 && N % 2 == 0 && ((out_misalign_bytes + (unsigned)(((long long)row_begin - out_row_origin) * N * 4)) & 7u) == 0;
     K3Shape sh;
     sh.nc = NC; sh.skips = 1; sh.faithful = FAITHFUL; sh.rows_per_task = ROWMAJOR ? 2 * NC : 0; sh.wgs_per_cu = wgs; sh.structs_per_segment = KS;
+    sh.vec = vec2;
     sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
-    return k3_go(go, ROWMAJOR ? "flat_rows" : "flat", name, sh, k3_flat<NP, SRC, NC, FAITHFUL, ROWMAJOR>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
+    return k3_go(go, MAP == 2 ? "flat_tiles" : ROWMAJOR ? "flat_rows" : "flat", name, sh, k3_flat<NP, SRC, NC, FAITHFUL, MAP>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
                  row_end, out_rows, out_row_origin, KS, tps, (unsigned)n_tasks, tasks_per_wg, (unsigned)((1ull << 32) / (unsigned)N), col_vec4,
-                 slot_vec4);
+                 slot_vec4, (unsigned)((1ull << 32) / std::max(1u, TC)), vec2);
 }
 
 // whether one structure's selected atoms fit the flat kernel's LDS (two workgroups per CU)
@@ -1166,8 +1239,10 @@ constexpr int K3_SWEEP_MIN_N = 100;
 // N = 63 276 / 344 us, 56 306 / 352, 48 333 / 371, 40 386 / 417, 33 480 / 449 (profiles/r05_featuriser_shapes.log)
 constexpr int K3_FEATURISE_MIN_N = 40;
 constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
-constexpr int K3_FLAT_UTIL_PERCENT = 78; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
-constexpr int K3_FLAT_UTIL_PERCENT_FAITHFUL = 90;   // (the faithful sweeps, two waves per SIMD, lose more to idle lanes: N = 160 149 us against ~110)
+constexpr int K3_FLAT_MAX_N = 256;        // ... up to this length (above it the fast sweeps are level with the tiles: 57-64 / 59-66 / 38-42 us)
+constexpr int K3_FLAT_MAX_N_FAITHFUL = 480;   // (faithful: N = 300 94 / 84 / 60 us against 117 / 97 / 66; from 500 on the sweeps win)
+constexpr int K3_FLAT_UTIL_PERCENT = 95; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
+constexpr int K3_FLAT_UTIL_PERCENT_FAITHFUL = 95;   // (the faithful sweeps, two waves per SIMD, lose even more to idle lanes: N = 160 149 us against 98)
 constexpr int K3_SMALL_MAX_N = 32;    // k3_small: one wave per structure (33..64 measured: no better than the one-column kernel)
 
 template <int NP, int SRC, bool FAITHFUL>
@@ -1223,7 +1298,9 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const bool allow4 = force_nc != 2;
     static const int flat_util = getenv("PS_K3_FLAT_UTIL") ? atoi(getenv("PS_K3_FLAT_UTIL")) : (FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT);
     static const int rows_min = getenv("PS_K3_ROWMAJOR_MIN") ? atoi(getenv("PS_K3_ROWMAJOR_MIN")) : K3_FLAT_ROWS_MIN_N;
+    static const int flat_max_n = getenv("PS_K3_FLAT_MAX_N") ? atoi(getenv("PS_K3_FLAT_MAX_N")) : (FAITHFUL ? K3_FLAT_MAX_N_FAITHFUL : K3_FLAT_MAX_N);
 #else
+    constexpr int flat_max_n = FAITHFUL ? K3_FLAT_MAX_N_FAITHFUL : K3_FLAT_MAX_N;
     const bool allow4 = true;
     constexpr int flat_util = FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT, rows_min = K3_FLAT_ROWS_MIN_N;
 #endif
@@ -1239,15 +1316,21 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     const bool vec = (ok4 || ok2) && !(SKIPS && gn * 115 < gv * 100);
     const int nc = vec ? ((NC4 && ok4 && (!ok2 || w4 <= w2)) ? 4 : 2) : ((NC4 && allow4 && (SKIPS ? gn > 2 : w4 <= w2)) ? 4 : 2);
     const long long g_eval = vec ? gv : (SKIPS ? gn : (nc == 4 ? w4 : w2) / 64);
-    // The flat kernel (every lane has an element whatever N is; ~70 us per 2^25 pairs at any length, profiles/r05_k3_shapes.log):
-    // every chain shorter than the sweeps' minimum, and up to 256 residues wherever fewer than K3_FLAT_UTIL_PERCENT of the
-    // sweep's lanes would have a column (N = 140: three groups of 64 for 140 columns, 69 against 102 us; the fast (2,2) dihedral
-    // at N = 160: four groups, 68 against 86).  Its column-per-lane map from 57 to 64 residues (70 against 77 us at N = 64).
+    // The flat kernel in its 2 x 2 tile map (every lane has an element whatever N is; 59-66 / 66-77 / 45-55 us per 2^25 pairs from
+    // 48 to 140 residues, profiles/r05_k3_shapes.log): every chain shorter than the sweeps' minimum, and up to 256 residues wherever
+    // fewer than K3_FLAT_UTIL_PERCENT of the sweep's lanes would have a column (N = 140: three groups of 64 for 140 columns,
+    // 59 against 102 us; N = 180: 59 / 66 / 46 against 61 / 74 / 50).
     if (!simple && N > small_max && N >= 32 && k3_flat_fits(N, A) &&
-        (N < K3_SWEEP_MIN_N || !fits || (N <= 256 && (long long)N * 100 < (long long)flat_util * 64 * g_eval))) {
-        if (N >= rows_min && N <= 64)
-            return launch_flat<NP, SRC, 4, FAITHFUL, true>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
-        return launch_flat<NP, SRC, 4, FAITHFUL, false>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, go);
+        (N < K3_SWEEP_MIN_N || !fits || (N <= flat_max_n && (long long)N * 100 < (long long)flat_util * 64 * g_eval))) {
+#ifdef PS_K3_AB
+        static const int flat_map = getenv("PS_K3_FLAT_MAP") ? atoi(getenv("PS_K3_FLAT_MAP")) : 2;
+        if (flat_map == 0 || (flat_map == 1 && !(N >= rows_min && N <= 64)))
+            return launch_flat<NP, SRC, 4, FAITHFUL, 0>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
+        if (flat_map == 1)
+            return launch_flat<NP, SRC, 4, FAITHFUL, 1>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
+#endif
+        (void)rows_min;
+        return launch_flat<NP, SRC, 4, FAITHFUL, 2>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
     }
     if (vec) {
         if constexpr (NC4) {

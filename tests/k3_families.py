@@ -28,16 +28,16 @@ K3_SHAPES = [
     (3, 16, CA_CB__CA_CB, None, False, 0, 0, arm("small", nc=16), True),
     (5, 20, N_CA_CB__CB, (3, 17), True, 0, 0, arm("small", nc=32), True),
     (2, 32, CA_CB__CB, None, False, 4, 0, arm("small", nc=32), True),
-    (3, 64, CA_CB__CA_CB, None, False, 0, 0, arm("flat_rows", nc=4, skips=1, wgs=2), True),
-    (700, 60, N_CA_CB__CB, None, False, 4, 0, arm("flat_rows", nc=4, skips=1, wgs=2), True),   # several staging passes per workgroup
-    (5, 57, C__N_CA_C, (4, 31), True, 0, 0, arm("flat_rows", nc=4, skips=1, wgs=2), True),
-    (700, 48, N_CA_CB__CB, None, False, 4, 0, arm("flat", nc=4, skips=1, wgs=2), True),
-    (5, 33, C__N_CA_C, (4, 31), True, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
-    (2, 140, CA_CB__CB, None, False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),            # three column groups for 140 columns: flat
-    (2, 130, CA_CB__CA_CB, (1, 130), False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
-    (2, 99, CA_CB__CB, (1, 98), False, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
-    (700, 65, N_CA_CB__CB, None, False, 4, 0, arm("flat", nc=4, skips=1, wgs=2), True),
-    (5, 80, C__N_CA_C, (4, 77), True, 0, 0, arm("flat", nc=4, skips=1, wgs=2), True),
+    (3, 64, CA_CB__CA_CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
+    (700, 60, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),   # several staging passes per workgroup
+    (5, 57, C__N_CA_C, (4, 31), True, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
+    (700, 48, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
+    (5, 33, C__N_CA_C, (4, 31), True, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
+    (2, 140, CA_CB__CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),            # three column groups for 140 columns: flat
+    (2, 130, CA_CB__CA_CB, (1, 130), False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
+    (2, 99, CA_CB__CB, (1, 98), False, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
+    (700, 65, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
+    (5, 80, C__N_CA_C, (4, 77), True, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
     (3, 64, CA_CB__CA_CB, None, False, 0, 2, arm("one_column"), True),
     (2, 256, N_CA_CB__CB, None, False, 0, 2, arm("one_column"), True),                       # the diagnostic bit
     (1, 50000, CA_CB__CB, (0, 13000), True, 0, 0, arm("one_column"), False),                 # 32-bit store offsets would overflow
@@ -52,11 +52,11 @@ K3_SHAPES = [
     (2, 301, N_CA_CB__CB, (7, 290), False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),
     (2, 511, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
     (2, 301, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
-    (3, 101, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
+    (3, 127, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=1), True),
     (2, 256, CA_CB__CB, None, False, 4, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),  # a 4-byte misaligned output
-    (2, 150, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),  # even N, but three groups instead of four
+    (2, 190, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=0, skips=1, wgs=1), True),  # even N, but three groups instead of four
     (2048, 128, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=1, wgs=2), True),     # two workgroups per CU
-    (2048, 101, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=2), True),
+    (2048, 127, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=2), True),
     (2, 512, ALL_I, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=1), True),
     (2048, 256, CA_CB__CB, None, False, 0, 0, arm("sweep", nc=4, vec=1, wgs=2), True),
     (2048, 255, CA_CB__CA_CB, None, False, 0, 0, arm("sweep", nc=2, vec=0, skips=1, wgs=2), True),
@@ -64,16 +64,18 @@ K3_SHAPES = [
     # ---- the reference's order of operations (bit 0 of exact_angles) ----
     (3, 16, CA_CB__CA_CB, None, False, 0, 1, arm("small", nc=16, faithful=1), True),
     (2, 31, CA_CB__CB, None, False, 0, 1, arm("small", nc=32, faithful=1), True),
-    (3, 64, N_CA_CB__CB, None, False, 0, 1, arm("flat_rows", nc=4, skips=1, faithful=1, wgs=2), True),
-    (700, 62, CA_CB__CB, (3, 50), False, 0, 1, arm("flat_rows", nc=4, skips=1, faithful=1, wgs=2), True),
-    (700, 50, CA_CB__CB, (3, 50), False, 0, 1, arm("flat", nc=4, skips=1, faithful=1, wgs=2), True),
-    (300, 90, CA_CB__CA_CB, (3, 90), False, 0, 1, arm("flat", nc=4, skips=1, faithful=1, wgs=2), True),
+    (3, 64, N_CA_CB__CB, None, False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
+    (700, 62, CA_CB__CB, (3, 50), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
+    (700, 50, CA_CB__CB, (3, 50), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
+    (300, 90, CA_CB__CA_CB, (3, 90), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
+    (40, 77, N_CA_CB__CB, None, False, 4, 1, arm("flat_tiles", nc=4, vec=0, skips=1, faithful=1, wgs=2), True),       # odd N: dword stores
     (2, 256, CA_CB__CA_CB, None, False, 0, 3, arm("one_column", faithful=1), True),
     (2, 512, CA_CB__CA_CB, None, False, 0, 1, arm("sweep", nc=4, vec=1, faithful=1, wgs=1), True),
     (2, 512, C__N_CA_C, None, False, 0, 1, arm("sweep", nc=4, vec=1, faithful=1, wgs=1), True),
     (2, 256, CA_CB__CB, None, False, 0, 1, arm("sweep", nc=4, vec=1, faithful=1, wgs=1), True),
     (2, 254, N_CA_CB__CB, None, False, 0, 1, arm("sweep", nc=2, vec=1, faithful=1, wgs=1), True),       # N % 4 != 0
-    (2, 301, CA_CB__CA_CB, (5, 300), True, 0, 1, arm("sweep", nc=4, vec=0, skips=1, faithful=1, wgs=1), True),
+    (2, 491, CA_CB__CA_CB, (5, 300), True, 0, 1, arm("sweep", nc=4, vec=0, skips=1, faithful=1, wgs=1), True),
+    (2, 301, CA_CB__CA_CB, (5, 300), True, 0, 1, arm("flat_tiles", nc=4, vec=0, skips=1, faithful=1, wgs=2), True),
     (3, 127, CA_CB__CB, None, False, 0, 1, arm("sweep", nc=2, vec=0, skips=1, faithful=1, wgs=1), True),
     (2048, 128, N_CA_CB__CB, None, False, 0, 1, arm("sweep", nc=2, vec=1, faithful=1, wgs=2), True),
     (2048, 256, CA_CB__CA_CB, None, False, 0, 1, arm("sweep", nc=4, vec=1, faithful=1, wgs=2), True),
