@@ -1017,9 +1017,10 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                 }
                 // !VEC: the last strip of a row may have fewer than NC live column groups (64 columns each) -- the chains of
                 // the dead ones are not evaluated (N = 129 at NC = 4: three of four; N = 300 at NC = 2: one of two)
+                int i_from = i0;
                 auto sweep_rows = [&](auto ncl_tag) {
                 constexpr int L = decltype(ncl_tag)::value;
-                for (int i = i0; i < i1; i += 2) {
+                for (int i = i_from; i < i1; i += 2) {
                     const int r = i >> 1;
                     const bool two = i + 1 < i1;                  // the last row of an odd N has no partner (uniform)
                     const f3v nv = {rowbuf[r * 9 + 0], rowbuf[r * 9 + 1], rowbuf[r * 9 + 2]};
@@ -1075,11 +1076,64 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
                     emit(r_th, v);
                 }
                 };
+                // One live column group (chains of up to 64 residues in the 64-apart layout): a lane has a single column, so its four
+                // interleaved chains are four consecutive ROW PAIRS instead of four columns (round 5; with one chain per lane the
+                // dependent instructions of a chain followed each other with nothing in between)
+                auto sweep_rows_by_row_pairs = [&]() {
+                    constexpr int R = 4;
+                    const f3v caj = mk3v(ca_j[0], ca_j[0]), cbj = mk3v(cb_j[0], cb_j[0]), oj = mk3v(o_j[0], o_j[0]);
+                    int i = i0;
+                    for (; i + 2 * R <= i1; i += 2 * R) {
+                        f3v NV[R], CAV[R], CBV[R], CAJ[R], CBJ[R];
+                        f32x2 v[R];
+#pragma unroll
+                        for (int q = 0; q < R; ++q) {
+                            const int r = (i >> 1) + q;
+                            NV[q] = f3v{rowbuf[r * 9 + 0], rowbuf[r * 9 + 1], rowbuf[r * 9 + 2]};
+                            CAV[q] = f3v{rowbuf[r * 9 + 3], rowbuf[r * 9 + 4], rowbuf[r * 9 + 5]};
+                            CBV[q] = f3v{rowbuf[r * 9 + 6], rowbuf[r * 9 + 7], rowbuf[r * 9 + 8]};
+                            CAJ[q] = caj; CBJ[q] = cbj;
+                        }
+                        const int so = i * row_bytes;
+                        auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&w)[R]) {
+#pragma unroll
+                            for (int q = 0; q < R; ++q) asm volatile("" : "+v"(w[q]));
+                            if (lv[0]) {
+#pragma unroll
+                                for (int q = 0; q < R; ++q) {
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w[q].x), rr, lane_off, so + 2 * q * row_bytes, POL);
+                                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(w[q].y), rr, lane_off, so + (2 * q + 1) * row_bytes, POL);
+                                }
+                            }
+                        };
+#pragma unroll
+                        for (int q = 0; q < R; ++q) v[q] = dist3v_t<EXACT>(CAV[q], caj);
+                        emit(r_dca, v);
+#pragma unroll
+                        for (int q = 0; q < R; ++q) v[q] = dist3v_t<EXACT>(CBV[q], cbj);
+                        emit(r_dcb, v);
+#pragma unroll
+                        for (int q = 0; q < R; ++q) v[q] = dist3v_t<EXACT>(NV[q], oj);
+                        emit(r_dno, v);
+                        if constexpr (FAITHFUL) angle3v_ref_n<R>(CAV, CBV, CBJ, v);
+                        else angle3v_n<R>(CAV, CBV, CBJ, v);
+                        emit(r_ph, v);
+                        if constexpr (FAITHFUL) dihedral4v_ref_n<R>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
+                        else dihedral4v_k3_n<R>(CAV, CBV, CAJ, CBJ, v);
+                        emit(r_om, v);
+                        if constexpr (FAITHFUL) dihedral4v_ref_n<R>(NV, CAV, CBV, CBJ, v);
+                        else dihedral4v_k3_n<R>(NV, CAV, CBV, CBJ, v);
+                        emit(r_th, v);
+                    }
+                    i_from = i;                                    // the task's remaining rows (fewer than eight): one pair at a time
+                    if (i < i1) sweep_rows(std::integral_constant<int, 1>{});
+                };
                 if constexpr (VEC) {
                     sweep_rows(std::integral_constant<int, NC>{});
                 } else {
                     const int ncl = min(NC, (N - strip * 64 * NC + 63) >> 6);   // live column groups of this strip (uniform)
-                    if (ncl == NC) sweep_rows(std::integral_constant<int, NC>{});
+                    if ((NC == 4 || FAITHFUL) && ncl == 1 && N <= 64) sweep_rows_by_row_pairs();   // (the instantiations with 256 VGPRs)
+                    else if (ncl == NC) sweep_rows(std::integral_constant<int, NC>{});
                     else if (NC == 4 && ncl == 3) sweep_rows(std::integral_constant<int, NC == 4 ? 3 : 1>{});
                     else if (NC == 4 && ncl == 2) sweep_rows(std::integral_constant<int, NC == 4 ? 2 : 1>{});
                     else sweep_rows(std::integral_constant<int, 1>{});
@@ -1479,7 +1533,7 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
         // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
         // 257 / 267; two groups, N = 101: 338 / 310)
-        if (!vec) NC = (CAN4 && gn > 2) ? 4 : 2;
+        if (!vec) NC = (CAN4 && (gn > 2 || N <= 64)) ? 4 : 2;   // (N <= 64: one column group, four row pairs per lane -- the 256-VGPR instantiation)
         const bool m16 = vec && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
         // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
         // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back
@@ -1495,7 +1549,8 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         // partial writes (2.2 % of the write requests at N = 500, none at N = 496: profiles/r04_featuriser_pmc.log);
         // same-box A/B, trace: N = 500 260 -> 228 us, 511 264 -> 241, 255 238 -> 218.
         const bool two_wg = (unsigned long long)B >= 4ull * cus;
-        const int CH = m16 ? 4 : 2;
+        // (chains of up to 64 residues in the 64-apart layout: eight rows, so that a lane's four chains are four row pairs)
+        const int CH = m16 ? 4 : (!vec && N <= 64) ? 8 : 2;
         const int n_chunks = (N + CH - 1) / CH;
         const unsigned long long n_tasks = (unsigned long long)n_chunks * n_strips * B;
         if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;

@@ -104,6 +104,8 @@ FEATURISER_SHAPES = [
     (3, 80, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=0, wgs=1), True),
     (3, 70, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wgs=1), True),
     (3, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wgs=1), True),
+    (3, 64, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=1), True),          # one column group: a lane's four chains are four row pairs
+    (1024, 47, 0, 3, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=2), True),
     (1024, 128, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=1, wgs=2), True),   # two workgroups per CU
     (1024, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wgs=2), True),
     (1024, 70, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wgs=2), True),
@@ -121,6 +123,7 @@ FEATURISER_SHAPES = [
     (2, 301, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=1), True),
     (1024, 128, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=2), True),
     (1024, 64, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=2), True),
+    (3, 60, 4, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=1), True),
     (1024, 70, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, faithful=1, wgs=2), True),
     (1024, 80, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=2), True),
 ]
