@@ -17,8 +17,8 @@
 //   k3_pairwise_angles   one column per lane, rows by scalar loads: the layout-free twin
 //                        every other kernel is held to bit for bit, and the fallback
 //   k3_small             N <= 32: one wave per structure
-//   k3_flat              33..99 residues (and wherever a sweep would idle its lanes): flat
-//                        over (row pair, column), several structures staged per pass
+//   k3_flat              33..99 residues (and wherever a sweep would idle its lanes): a lane's
+//                        element is a 2 x 2 tile (row pairs x columns), several structures staged per pass
 //   k3_sweep             >= 100 residues: one workgroup per CU, rows staged in LDS, tasks
 //                        pulled from an LDS counter, NC column residues per lane
 //   k3_inter_residue_geometry, k3_featurise   the fused featuriser: one-column / sweep
@@ -222,24 +222,27 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
     }
 }
 
-// Chains of 33 .. ~100 residues (round 5): FLAT over (row pair, column), several structures per staging pass.
+// Chains of 33 .. ~100 residues, and longer ones wherever a sweep would idle its lanes (round 5): several structures per
+// staging pass, every lane busy whatever N is.
 // The per-CU sweep gives a wave a strip of 64 * NC columns of ONE structure: below ~100 residues most lanes of a strip have no
 // column, a (structure, strip) segment has fewer tasks than the workgroup has waves, and every segment costs two barriers and
 // a round trip to L2 (N = 64: 143 us at 2^25 pairs, which is why such chains stayed with the one-column kernel: 85 us).  Here
-//   * a lane's element is a flat index f = row pair * N + column of one structure (64 consecutive f per store instruction, NC
-//     of them 64 apart per lane, their chains interleaved): every lane has work whatever N is;
 //   * the selected atoms of KS structures are staged at once (column-side atoms as {x, y, z, -} per (atom, residue), row-side
 //     atoms pair-interleaved as {x0, x1, y0, y1}, {z0, z1, -, -} per (row pair, atom): every read in the loop is 16 bytes),
 //     so the two barriers and the load latency of a pass are paid once per KS * N * N pairs instead of once per 4 096;
-//   * TWO 512-thread workgroups share a CU and a workgroup's share takes four or more passes: at these lengths the input is
-//     2.8 bytes per pair (N = 64) against 4 written, and while one workgroup waits for its next structures the other computes
-//     (one 1024-thread workgroup that staged its whole share first: 74 us at N = 64, of which ~20 were that wait; a plain
-//     coalesced copy of the coordinates instead of the gather of the selected atoms: 88 us -- it reads all 15 atoms);
-//   * both sides of a pair come from LDS per lane: lanes of one row pair read the same address (a broadcast), the column side
-//     is consecutive 16-byte words (no bank conflict);
-//   * tasks of 64 * NC flat elements are pulled from an LDS counter, as in the sweep; stores are unconditional (a dead
-//     element's offset lies beyond the buffer descriptor's range and the hardware drops it), so the NC chains stay in one
-//     basic block and interleave.
+//   * TWO 512-thread workgroups share a CU and a workgroup's share takes four or more passes: while one workgroup waits for
+//     its next structures the other computes;
+//   * both sides of a pair come from LDS per lane (lanes of one row pair read the same address: a broadcast);
+//   * tasks are pulled from an LDS counter, as in the sweep; stores are unconditional (a dead element's offset lies beyond the
+//     buffer descriptor's range and the hardware drops it), so the four chains stay in one basic block and interleave.
+// Lane maps (MAP).  2, the product's: a lane's element is a 2 x 2 TILE -- two row pairs x two adjacent columns, four chains --
+// so that what depends on the row pair alone is shared by the tile's two columns and what depends on the column alone by
+// its two row pairs (as in the sweep), the index arithmetic is paid once per tile and two columns are one 8-byte store:
+// ~300 VALU instructions per 8 pairs, 57-64 us per 2^25 pairs from 64 to 220 residues.  0 and 1 (tools only, -DPS_K3_AB): NC
+// elements 64 apart in the flat index (row pair, column) -- 408 instructions per 8 pairs, 68-77 us -- and a lane per column
+// with NC consecutive row pairs (N <= 64: 324 instructions, 69 us at N = 64); profiles/r05_k3_flat_lane_maps.log.  Also tried:
+// a plain coalesced copy of the coordinates instead of the gather of the selected atoms (88 us: it reads all 15 atoms), one
+// 1024-thread workgroup staging its whole share at once (74 us) -- NOTES.md.
 // Same arithmetic per pair as the one-column kernel: same bits.
 template <int NP, int SRC, int NC, bool FAITHFUL, int MAP>
 __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
