@@ -1152,6 +1152,177 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
     }
 }
 
+// The featuriser on the TILE map of k3_flat (round 5): a lane's element is two row pairs x two adjacent columns of one structure
+// (four interleaved chains per feature), the N / CA / CB row atoms, CA / O / CB column atoms and the six mask bits per residue of
+// KS structures staged per pass, two workgroups per CU, tasks of 64 tiles pulled from an LDS counter.  Chains of up to a few hundred
+// residues: every lane has work whatever N is, what depends on a row pair or a column alone is shared inside the tile, and
+// the set-up of a structure is paid once per KS structures.  Float planes: 8-byte stores of the tile's two columns (N even, planes
+// 8-byte aligned; else dword stores); mask planes: two bytes per row of the tile (N even, planes 2-byte aligned; else bytes).
+// Same arithmetic per pair as k3_inter_residue_geometry: same bits.
+template <bool EXACT, bool FAITHFUL>
+__global__ __launch_bounds__(512) void k3_featurise_tiles(
+    const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
+    float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
+    float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
+    int A, int KS, unsigned tps, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, unsigned rcpTC, int slot_vec4, int vec2f,
+    int vec2m) {
+    // [slot]: column atoms CA, O, CB as {x, y, z, -} per (atom, residue): 3 N vec4; row atoms N, CA, CB pair-interleaved
+    // {x0, x1, y0, y1}, {z0, z1, -, -} per (row pair, atom): 6 RP vec4; then one byte per residue: bits 0..2 = row side
+    // (N, CA, CB present), bits 4..6 = column side (CA, CB, O present)
+    extern __shared__ __attribute__((aligned(16))) k3_f32x4 k3_tilebuf[];
+    __shared__ unsigned next_task;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned n_waves = blockDim.x >> 6;
+    const unsigned t0 = blockIdx.x * tasks_per_wg, t1 = min(t0 + tasks_per_wg, n_tasks);
+    if (t0 >= t1) return;                         // whole workgroup
+    const int n_rp = (N + 1) >> 1;
+    const int col_vec4 = 3 * N, row_vec4 = 6 * n_rp;
+    const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
+    const unsigned b_first = t0 / tps, b_last = (t1 - 1u) / tps;
+    for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS) {
+        const unsigned ks = min((unsigned)KS, b_last - bs + 1u);
+        __syncthreads();                                          // the previous pass's readers are done
+        for (unsigned it = threadIdx.x; it < ks * (unsigned)N; it += blockDim.x) {   // one residue of one structure per thread
+            unsigned sidx = __umulhi(it, rcpN), r = it - sidx * (unsigned)N;
+            if (r >= (unsigned)N) ++sidx, r -= (unsigned)N;
+            const float* pr = xyz + ((size_t)(bs + sidx) * N + r) * (size_t)A * 3;
+            k3_f32x4* slot = k3_tilebuf + (size_t)sidx * slot_vec4;
+            const float v[15] = {pr[0], pr[1], pr[2], pr[3], pr[4], pr[5], pr[9], pr[10], pr[11], pr[12], pr[13], pr[14]};   // N, CA, O, CB
+            unsigned bits = 0x77u;
+            if (amask) {
+                const uint8_t* mr = amask + ((size_t)(bs + sidx) * N + r) * A;
+                const unsigned mn = mr[0] != 0, mca = mr[1] != 0, mo = mr[3] != 0, mcb = mr[4] != 0;
+                bits = mn | (mca << 1) | (mcb << 2) | (mca << 4) | (mcb << 5) | (mo << 6);
+            }
+            slot[0 * N + (int)r] = k3_f32x4{v[3], v[4], v[5], 0.0f};        // CA
+            slot[1 * N + (int)r] = k3_f32x4{v[6], v[7], v[8], 0.0f};        // O
+            slot[2 * N + (int)r] = k3_f32x4{v[9], v[10], v[11], 0.0f};      // CB
+            float* rb = reinterpret_cast<float*>(slot + col_vec4) + (size_t)(r >> 1) * 24 + (r & 1);
+            rb[0] = v[0]; rb[2] = v[1]; rb[4] = v[2];                       // N
+            rb[8] = v[3]; rb[10] = v[4]; rb[12] = v[5];                     // CA
+            rb[16] = v[9]; rb[18] = v[10]; rb[20] = v[11];                  // CB
+            reinterpret_cast<uint8_t*>(slot + col_vec4 + row_vec4)[r] = (uint8_t)bits;
+        }
+        const unsigned seg_t0 = max(t0, bs * tps), seg_t1 = min(t1, (bs + ks) * tps);
+        if (threadIdx.x == 0) next_task = seg_t0 + n_waves;       // the first n_waves tasks are pre-assigned
+        __syncthreads();
+        unsigned t = seg_t0 + (unsigned)wave;
+        while (t < seg_t1) {
+            const unsigned b = t / tps, chunk = t - b * tps;      // (uniform)
+            const k3_f32x4* slot = k3_tilebuf + (size_t)(b - bs) * slot_vec4;
+            const k3_f32x4* rowp = slot + col_vec4;
+            const uint8_t* mbits = reinterpret_cast<const uint8_t*>(slot + col_vec4 + row_vec4);
+            const size_t sbase = (size_t)b * N * N;
+            auto rs = [&](void* base, unsigned bytes) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000u); };
+            const unsigned fbytes = (unsigned)N * (unsigned)N * 4u, mbytes = (unsigned)N * (unsigned)N;   // this structure's planes, exactly
+            const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + sbase, fbytes), r_dcb = rs(d_cb + sbase, fbytes), r_dno = rs(d_no + sbase, fbytes),
+                                         r_om = rs(omega + sbase, fbytes), r_th = rs(theta + sbase, fbytes), r_ph = rs(phi + sbase, fbytes);
+            const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + sbase, mbytes), r_mcb = rs(m_cb + sbase, mbytes), r_mno = rs(m_no + sbase, mbytes);
+            const unsigned ti = chunk * 64u + (unsigned)lane;
+            const bool lt = ti < FT;
+            const unsigned tcl = min(ti, FT - 1u);
+            unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
+            if (tc >= TC) ++tr, tc -= TC;
+            const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
+            const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
+            const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
+            // rows 2 rpA (always there), 2 rpA + 1, 2 rpB, 2 rpB + 1
+            const int iA0 = 2 * rpA, iA1 = min(iA0 + 1, N - 1), iB0 = 2 * rpB, iB1 = min(iB0 + 1, N - 1);
+            const bool rA1 = iA0 + 1 < N, rB0 = lrB, rB1 = lrB && iB0 + 1 < N;
+            f3v NV[4], CAV[4], CBV[4], CAJ[4], CBJ[4], OJ[4];
+            {
+                const k3_f32x4 ca0 = slot[c0], ca1 = slot[c1], o0 = slot[N + c0], o1 = slot[N + c1], cb0 = slot[2 * N + c0], cb1 = slot[2 * N + c1];
+                CAJ[0] = CAJ[2] = mk3v(f3{ca0.x, ca0.y, ca0.z}, f3{ca0.x, ca0.y, ca0.z});
+                CAJ[1] = CAJ[3] = mk3v(f3{ca1.x, ca1.y, ca1.z}, f3{ca1.x, ca1.y, ca1.z});
+                OJ[0] = OJ[2] = mk3v(f3{o0.x, o0.y, o0.z}, f3{o0.x, o0.y, o0.z});
+                OJ[1] = OJ[3] = mk3v(f3{o1.x, o1.y, o1.z}, f3{o1.x, o1.y, o1.z});
+                CBJ[0] = CBJ[2] = mk3v(f3{cb0.x, cb0.y, cb0.z}, f3{cb0.x, cb0.y, cb0.z});
+                CBJ[1] = CBJ[3] = mk3v(f3{cb1.x, cb1.y, cb1.z}, f3{cb1.x, cb1.y, cb1.z});
+                auto row_atom = [&](int rp, int q) {
+                    const k3_f32x4 xy = rowp[(rp * 3 + q) * 2];
+                    const f32x2 z = *reinterpret_cast<const f32x2*>(rowp + (rp * 3 + q) * 2 + 1);
+                    return f3v{f32x2{xy.x, xy.y}, f32x2{xy.z, xy.w}, z};
+                };
+                NV[0] = NV[1] = row_atom(rpA, 0); CAV[0] = CAV[1] = row_atom(rpA, 1); CBV[0] = CBV[1] = row_atom(rpA, 2);
+                NV[2] = NV[3] = row_atom(rpB, 0); CAV[2] = CAV[3] = row_atom(rpB, 1); CBV[2] = CBV[3] = row_atom(rpB, 2);
+            }
+            constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
+            const int offA = (int)__umul24((unsigned)iA0, (unsigned)N) + c0, offB = (int)__umul24((unsigned)iB0, (unsigned)N) + c0;   // in elements
+            const bool l1 = lt && lc1;
+            // one plane's four chains: {v[0], v[1]} = row pair A x columns c0, c1; {v[2], v[3]} = row pair B; .x / .y = the pair's rows
+            auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[4]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
+                if (vec2f) {     // (uniform)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rr, lt ? offA * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rr, (lt && rA1) ? (offA + N) * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rr, (lt && rB0) ? offB * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].y, v[3].y}), rr, (lt && rB1) ? (offB + N) * 4 : DEAD, 0, 0);
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].x), rr, lt ? offA * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].x), rr, l1 ? offA * 4 + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].y), rr, (lt && rA1) ? (offA + N) * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].y), rr, (l1 && rA1) ? (offA + N) * 4 + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].x), rr, (lt && rB0) ? offB * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].x), rr, (l1 && rB0) ? offB * 4 + 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].y), rr, (lt && rB1) ? (offB + N) * 4 : DEAD, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].y), rr, (l1 && rB1) ? (offB + N) * 4 + 4 : DEAD, 0, 0);
+                }
+            };
+            // the three mask planes first (their stores drain while the arithmetic runs): rows' bits 0..2 = N, CA, CB; columns' bits 4..6 = CA, CB, O
+            {
+                const unsigned mA0 = mbits[iA0], mA1 = mbits[iA1], mB0 = mbits[iB0], mB1 = mbits[iB1], mc0 = mbits[c0] >> 4, mc1 = mbits[c1] >> 4;
+                auto plane = [&](const __amdgpu_buffer_rsrc_t& rr, unsigned rbit, unsigned cbit) {
+                    const unsigned k0 = (mc0 >> cbit) & 1u, k1 = (mc1 >> cbit) & 1u;
+                    const unsigned a0 = (mA0 >> rbit) & 1u, a1 = (mA1 >> rbit) & 1u, b0 = (mB0 >> rbit) & 1u, b1 = (mB1 >> rbit) & 1u;
+                    if (vec2m) {     // (uniform) two bytes per row of the tile
+                        const unsigned kk = k0 | (k1 << 8);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(a0 ? kk : 0u), rr, lt ? offA : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(a1 ? kk : 0u), rr, (lt && rA1) ? offA + N : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(b0 ? kk : 0u), rr, (lt && rB0) ? offB : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(b1 ? kk : 0u), rr, (lt && rB1) ? offB + N : DEAD, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(a0 & k0), rr, lt ? offA : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(a0 & k1), rr, l1 ? offA + 1 : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(a1 & k0), rr, (lt && rA1) ? offA + N : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(a1 & k1), rr, (l1 && rA1) ? offA + N + 1 : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(b0 & k0), rr, (lt && rB0) ? offB : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(b0 & k1), rr, (l1 && rB0) ? offB + 1 : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(b1 & k0), rr, (lt && rB1) ? offB + N : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(b1 & k1), rr, (l1 && rB1) ? offB + N + 1 : DEAD, 0, 0);
+                    }
+                };
+                plane(r_mca, 1u, 0u);      // CA_i & CA_j
+                plane(r_mcb, 2u, 1u);      // CB_i & CB_j
+                plane(r_mno, 0u, 2u);      // N_i & O_j
+            }
+            f32x2 v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(CAV[c], CAJ[c]);
+            emit(r_dca, v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(CBV[c], CBJ[c]);
+            emit(r_dcb, v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(NV[c], OJ[c]);
+            emit(r_dno, v);
+            if constexpr (FAITHFUL) angle3v_ref_n<4>(CAV, CBV, CBJ, v);
+            else angle3v_n<4>(CAV, CBV, CBJ, v);
+            emit(r_ph, v);
+            if constexpr (FAITHFUL) dihedral4v_ref_n<4>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
+            else dihedral4v_k3_n<4>(CAV, CBV, CAJ, CBJ, v);
+            emit(r_om, v);
+            if constexpr (FAITHFUL) dihedral4v_ref_n<4>(NV, CAV, CBV, CBJ, v);
+            else dihedral4v_k3_n<4>(NV, CAV, CBV, CBJ, v);
+            emit(r_th, v);
+            unsigned nx = 0;
+            if (lane == 0) nx = atomicAdd(&next_task, 1u);
+            t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
+        }
+    }
+}
+
 // Rows per task (even, 2..8).  The 16 waves of a workgroup pull the tasks of one (structure, strip) segment at a time, and
 // the pulling only evens out the SIMD arbiter's oldest-first order if a segment has several tasks per wave: a segment of
 // `rows` rows gets about 64 tasks (N = 512: 8 rows per task, 256: 4, 128: 2; with one task per wave a 128-residue segment
@@ -1295,6 +1466,14 @@ constexpr int K3_SWEEP_MIN_N = 100;
 // several structures per staging pass) pays from 40 on: same-box, 2^25 pairs, min of 20 launches, sweep / one-column kernel:
 // N = 63 276 / 344 us, 56 306 / 352, 48 333 / 371, 40 386 / 417, 33 480 / 449 (profiles/r05_featuriser_shapes.log)
 constexpr int K3_FEATURISE_MIN_N = 40;
+// the featuriser's tile kernel: chain lengths it takes (same-box A/B against the sweep and the one-column kernel: profiles/r05_featuriser_shapes.log)
+// same box, 2^25 pairs, min of 20 launches, tiles / product before: N = 16 428 / 666 us, 24 372 / 605, 33 363 / 433, 40 271 / 355,
+// 48 258 / 297, 64 224 / 234, 80 233 / 277, 99 265 / 267, 100 243-275 / 252, 129 262 / 339, 160 211 / 280, 200 221-245 / 232;
+// the sweep wins where its lanes are full (128: 185 against 206, 256: 161 / 194) and at odd lengths above ~100 (101: 272 / 288:
+// the tiles' stores are dwords and bytes there)
+constexpr int K3F_TILES_MIN_N = 8, K3F_TILES_MAX_N = 96;     // every chain of 8 .. 96 residues ...
+constexpr int K3F_TILES_MAX_N_EVEN = 200, K3F_TILES_UTIL_PERCENT = 85;   // ... and even lengths up to 200 where < 85 % of the sweep's lanes would have a column
+constexpr unsigned K3F_TILES_WGS = 2;                        // (2 / 3 / 4 workgroups per CU: no difference beyond noise)
 constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
 constexpr int K3_FLAT_MAX_N = 256;        // ... up to this length (above it the fast sweeps are level with the tiles: 57-64 / 59-66 / 38-42 us)
 constexpr int K3_FLAT_MAX_N_FAITHFUL = 480;   // (faithful: N = 300 94 / 84 / 60 us against 117 / 97 / 66; from 500 on the sweeps win)
@@ -1515,6 +1694,51 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
     // one structure's rows (points + mask words), its column points, its column masks (bytes or bit sets)
     const size_t need = (size_t)((N + 2) / 2) * (9 * 8 + 4) + 32 + 16 + (size_t)((N + 3) & ~3) * 36 +
                         std::max<size_t>(3 * (size_t)N, 3 * ((size_t)(N + 31) / 32 + 2) * 4) + 16;
+    // Chains of K3F_TILES_MIN_N .. K3F_TILES_MAX_N residues: the tile kernel (several structures per pass, every lane busy)
+#ifdef PS_K3_AB
+    static const int tiles_min = getenv("PS_K3F_TILES_MIN") ? atoi(getenv("PS_K3F_TILES_MIN")) : K3F_TILES_MIN_N;
+    static const int tiles_max = getenv("PS_K3F_TILES_MAX") ? atoi(getenv("PS_K3F_TILES_MAX")) : K3F_TILES_MAX_N;
+#else
+    constexpr int tiles_min = K3F_TILES_MIN_N, tiles_max = K3F_TILES_MAX_N;
+#endif
+    {
+        const int n_rp = (N + 1) / 2;
+        const size_t slot_vec4 = (size_t)3 * N + (size_t)6 * n_rp + ((size_t)N + 15) / 16;   // column atoms, row atoms, one byte per residue
+        // (odd lengths -- dword and byte stores in the tile kernel -- only below 70 %: N = 129 262 against 339 us, but 101 288 against 272)
+        const bool tiles_even = N <= K3F_TILES_MAX_N_EVEN && (long long)N * 100 < (long long)(N % 2 == 0 ? K3F_TILES_UTIL_PERCENT : 70) * 64 * ((N + 63) / 64);
+        if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
+            (unsigned long long)N * N < (1ull << 29)) {
+            const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(n_rp + 1) / 2;
+            const unsigned tps = (TR * TC + 63u) / 64u;
+            const unsigned long long n_tasks = (unsigned long long)tps * B;
+            if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
+#ifdef PS_K3_AB
+            static const unsigned tiles_wgs = getenv("PS_K3F_TILES_WGS") ? (unsigned)atoi(getenv("PS_K3F_TILES_WGS")) : K3F_TILES_WGS;
+#else
+            constexpr unsigned tiles_wgs = K3F_TILES_WGS;
+#endif
+            // K3F_TILES_WGS 256-thread workgroups per CU (their LDS requests admit exactly that many; 132 / 167 VGPRs: three waves per SIMD)
+            const size_t tiles_lds = tiles_wgs == 2 ? K3_LDS_TWO_PER_CU : ((size_t)160 * 1024 / tiles_wgs - 256) & ~(size_t)255;
+            const unsigned slots = (unsigned)go.cus * tiles_wgs;
+            const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + slots - 1) / slots, 4ull);
+            const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
+            const unsigned share = (tasks_per_wg + tps - 1) / tps + 1;
+            const int KS = (int)std::max<size_t>(1, std::min<size_t>(tiles_lds / (slot_vec4 * 16), (share + 3) / 4));
+            const int vec2f = N % 2 == 0 && (alf & 7u) == 0, vec2m = N % 2 == 0 && (alm & 1u) == 0;
+            char name[96];
+            snprintf(name, sizeof name, "k3_featurise_tiles<EXACT=%d,FAITHFUL=%d>", exact_sqrt, (int)FAITHFUL);
+            K3Shape sh;
+            sh.nc = 4; sh.vec = vec2f; sh.skips = 1; sh.mask_mode = vec2m ? 3 : 0; sh.faithful = FAITHFUL; sh.wgs_per_cu = (int)tiles_wgs; sh.structs_per_segment = KS;
+            sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
+            static unsigned long long prep[2][1] = {{0}, {0}};
+            auto tiles = [&](auto kernel, unsigned long long (&prepared)[1]) {
+                return k3_go(go, "featurise_tiles", name, sh, kernel, &prepared, dim3(grid), dim3(256), tiles_lds, 4u, xyz, atom_mask, d_ca, d_cb,
+                             d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, KS, tps, (unsigned)n_tasks, tasks_per_wg,
+                             (unsigned)((1ull << 32) / (unsigned)N), (unsigned)((1ull << 32) / std::max(1u, TC)), (int)slot_vec4, vec2f, vec2m);
+            };
+            return exact_sqrt ? tiles(k3_featurise_tiles<true, FAITHFUL>, prep[0]) : tiles(k3_featurise_tiles<false, FAITHFUL>, prep[1]);
+        }
+    }
     // the per-CU sweep: any N >= K3_FEATURISE_MIN_N whose rows fit in LDS
 #ifdef PS_K3_AB
     static const int feat_min_n = getenv("PS_K3F_MIN_N") ? atoi(getenv("PS_K3F_MIN_N")) : K3_FEATURISE_MIN_N;

@@ -8,7 +8,7 @@ report over a sweep of shapes is missing from the table; ``tests/test_gpu_parity
 arithmetic: the conditioning gate of SURVEY hard part 3; faithful: no dihedral beyond 1e-5) inside sentinel buffers.
 
 An arm = (family, columns_per_lane, vector_stores, skips_dead_groups, faithful, workgroups_per_cu) for K3, plus
-(mask_store_mode, write_through) for the featuriser.  All plans are taken at 256 compute units (MI355X)."""
+(mask_store_mode, write_through) for the featuriser (families featurise, featurise_tiles, one_column).  All plans are taken at 256 compute units (MI355X)."""
 
 CA_CB__CA_CB = (4, [1, 4], [1, 4])       # (2,2) dihedral, SRC = 12
 N_CA_CB__CB = (4, [0, 1, 4], [4])        # (3,1) dihedral, SRC = 8
@@ -91,41 +91,52 @@ def farm(family, nc=1, vec=0, mask=0, wt=0, faithful=0, wgs=0):
 
 # (B, N, float plane misalignment in bytes, mask plane misalignment, exact_angles, expected arm, run on the GPU)
 FEATURISER_SHAPES = [
-    (3, 39, 0, 0, 0, farm("one_column"), True),
-    (2, 256, 0, 0, 2, farm("one_column"), True),
-    (1, 2200, 0, 0, 0, farm("one_column"), True),                                   # rows + column points + masks beyond the LDS
+    (3, 5, 0, 0, 0, farm("one_column"), True),   # below the tile kernel's minimum
+    (2, 256, 0, 0, 2, farm("one_column"), True),   # the diagnostic bit
+    (1, 2200, 0, 0, 0, farm("one_column"), True),   # rows + column points + masks beyond the LDS
+    (3, 5, 0, 0, 1, farm("one_column", faithful=1), True),
+    (2, 256, 0, 0, 3, farm("one_column", faithful=1), True),
+    (3, 48, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # 8-byte float stores, 2-byte mask stores
+    (700, 64, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # several staging passes per workgroup
+    (3, 33, 0, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, wgs=2), True),   # odd N: dword and byte stores
+    (3, 80, 4, 3, 0, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, wgs=2), True),   # planes on 4-byte / odd boundaries
+    (3, 48, 0, 5, 0, farm("featurise_tiles", nc=4, vec=1, mask=0, wt=0, wgs=2), True),
+    (3, 48, 4, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=3, wt=0, wgs=2), True),
+    (2, 160, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # even N, 83 % of a sweep's lanes
+    (2, 200, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),
+    (3, 48, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
+    (700, 64, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
+    (3, 80, 4, 3, 1, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, faithful=1, wgs=2), True),
+    (3, 48, 0, 5, 1, farm("featurise_tiles", nc=4, vec=1, mask=0, wt=0, faithful=1, wgs=2), True),
+    (3, 60, 4, 0, 1, farm("featurise_tiles", nc=4, vec=0, mask=3, wt=0, faithful=1, wgs=2), True),
+    (3, 39, 0, 0, 1, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, faithful=1, wgs=2), True),
     (2, 512, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=2, wt=1, wgs=1), True),   # BASELINE config 3's layout
     (2, 496, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=2, wt=0, wgs=1), True),
-    (2, 500, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=1, wgs=1), True),
-    (2, 512, 0, 5, 0, farm("featurise", nc=4, vec=1, mask=1, wgs=1), True),         # mask planes off the 16-byte grid
-    (2, 301, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=1), True),
-    (2, 512, 4, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=1), True),         # float planes on a 4-byte boundary only
-    (3, 128, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=1, wgs=1), True),
-    (3, 80, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=0, wgs=1), True),
-    (3, 70, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wgs=1), True),
-    (3, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wgs=1), True),
-    (3, 64, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=1), True),          # one column group: a lane's four chains are four row pairs
-    (1024, 47, 0, 3, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=2), True),
-    (1024, 128, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=1, wgs=2), True),   # two workgroups per CU
-    (1024, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wgs=2), True),
-    (1024, 70, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wgs=2), True),
-    (1024, 80, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=0, wgs=2), True),
-    (1024, 129, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wgs=2), True),
-    (1024, 200, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=1, wgs=2), True),
+    (2, 500, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=1, wt=0, wgs=1), True),
+    (2, 512, 0, 5, 0, farm("featurise", nc=4, vec=1, mask=1, wt=0, wgs=1), True),   # mask planes off the 16-byte grid
+    (2, 301, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wt=0, wgs=1), True),
+    (2, 512, 4, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wt=0, wgs=1), True),   # float planes on a 4-byte boundary only
+    (1024, 191, 0, 0, 0, farm("featurise", nc=4, vec=0, mask=1, wt=0, wgs=2), True),   # two workgroups per CU
+    (3, 129, 0, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, wgs=2), True),   # odd N, 67 % of a sweep's lanes
+    (1024, 256, 0, 5, 0, farm("featurise", nc=4, vec=1, mask=1, wt=0, wgs=2), True),
     (1024, 256, 16, 16, 0, farm("featurise", nc=4, vec=1, mask=2, wt=0, wgs=2), True),
     (1024, 256, 0, 0, 0, farm("featurise", nc=4, vec=1, mask=2, wt=1, wgs=2), True),
-    # ---- the reference's order of operations: two columns per lane ----
-    (3, 39, 0, 0, 1, farm("one_column", faithful=1), True),
-    (2, 256, 0, 0, 3, farm("one_column", faithful=1), True),
+    (3, 128, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=1, wgs=1), True),
+    (3, 112, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=0, wgs=1), True),
+    (3, 110, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wt=0, wgs=1), True),
+    (3, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wt=0, wgs=1), True),
+    (1024, 128, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=1, wgs=2), True),
+    (1024, 112, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=2, wt=0, wgs=2), True),
+    (1024, 110, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wt=0, wgs=2), True),
+    (1024, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wt=0, wgs=2), True),
     (2, 512, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=1), True),
     (2, 496, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=1), True),
-    (2, 500, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, faithful=1, wgs=1), True),
-    (2, 301, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=1), True),
+    (2, 500, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, wt=0, faithful=1, wgs=1), True),
+    (2, 301, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, wt=0, faithful=1, wgs=1), True),
     (1024, 128, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=2), True),
-    (1024, 64, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=2), True),
-    (3, 60, 4, 0, 1, farm("featurise", nc=2, vec=0, mask=1, faithful=1, wgs=1), True),
-    (1024, 70, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, faithful=1, wgs=2), True),
-    (1024, 80, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=2), True),
+    (1024, 112, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=2), True),
+    (1024, 110, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, wt=0, faithful=1, wgs=2), True),
+    (1024, 101, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, wt=0, faithful=1, wgs=2), True),
 ]
 
 
