@@ -1,6 +1,7 @@
 #!/usr/bin/python3
 """Workloads for rocprofv3 (run as `rocprofv3 ... -- python3 tools/profile_workload.py <what> [reps]`):
 
+    featshort  the featuriser at 2^25 pairs for N = 64, 48, 160 (tile kernel), 128 and 512 (sweep)
     k3flat  K3 dihedral (2,2) and planar (2,1) at 2^25 pairs for N = 64, 99, 48 (flat kernel) and 512 (sweep)
     k3p     the same as k3, host-paced (a synchronise after every launch)
     k3      BASELINE config 3 (B=128, N_res=512): pairwise_dihedrals (2,2) CA,CB|CA,CB and (3,1) N,CA,CB|CB,
@@ -65,6 +66,12 @@ elif what == "k3flat":      # the flat K3 kernel at 2^25 pairs: N = 64 (column-p
         out = torch.empty(b, n, n, device="cuda")
         repeat(lambda: ops.pairwise_angles(xyz, [1, 4], [1, 4], 4, out=out))
         repeat(lambda: ops.pairwise_angles(xyz, [1, 4], [4], 3, out=out))
+elif what == "featshort":   # the featuriser at 2^25 pairs: N = 64, 48, 160 (tile kernel), 128, 512 (sweep)
+    for n in (64, 48, 160, 128, 512):
+        b = (1 << 25) // (n * n)
+        xyz, mask = synth(b, n)
+        sbn = StructureBatch.from_xyz(xyz, mask)
+        repeat(lambda: sbn.inter_residue_geometry())
 elif what == "k5":
     xyz, mask = synth(256, 384)
     sb = StructureBatch.from_xyz(xyz, mask).manual_seed(1)
