@@ -573,9 +573,11 @@ def other_configs(dev, steps):
                     us = sum(ts) / len(ts)
                     plan = _lib.k3_plan(b, n, N_ATOM, si, sj, npts, out_misalign=outbuf.data_ptr() % 16, exact_angles=mode, cu_count=cus)
                     vb = bounds.get("kernels", {}).get(plan["kernel"], {}).get("valu_bound_us")
+                    ib = bounds.get("kernels", {}).get(plan["kernel"], {}).get("issue_bound_us")
                     legs[key] = {"kernel": plan["kernel"], "us": us, "us_min_max": [min(ts), max(ts)], "us_back_to_back_train": train,
                                  "G_pairs_per_s": b * n * n / us / 1e3, "frac_of_hbm_peak": b * n * n * 4 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                  "valu_bound_us": vb, "frac_of_valu_bound": (vb / us) if vb else None,
+                                 "issue_bound_us": ib, "frac_of_issue_bound": (ib / us) if ib else None,
                                  "check": "ok" if ok else f"frac > 1e-5: {frac_bad:.2e}, NaN positions equal: {nan_equal}",
                                  "max_abs_err_vs_oracle": err[both].max().item(), "frac_off_diagonal_beyond_1e-5": frac_bad,
                                  "nan_positions_equal_to_oracle": nan_equal}
@@ -597,10 +599,12 @@ def other_configs(dev, steps):
                 us = sum(ts) / len(ts)
                 plan = _lib.featuriser_plan(b, n, N_ATOM, exact_sqrt=_lib.get_tuning("k1_exact_sqrt", dev), exact_angles=mode, cu_count=cus)
                 vb = bounds.get("kernels", {}).get(plan["kernel"], {}).get("valu_bound_us")
+                ib = bounds.get("kernels", {}).get(plan["kernel"], {}).get("issue_bound_us")
                 legs["inter_residue_geometry"] = {"kernel": plan["kernel"], "us": us, "us_min_max": [min(ts), max(ts)], "us_back_to_back_train": train,
                                                   "G_pairs_per_s": b * n * n / us / 1e3,
                                                   "frac_of_hbm_peak": b * n * n * 27 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
                                                   "valu_bound_us": vb, "frac_of_valu_bound": (vb / us) if vb else None,
+                                                  "issue_bound_us": ib, "frac_of_issue_bound": (ib / us) if ib else None,
                                                   "check": "ok" if ok else "a plane differs from its K3 launch / the distance formula / the mask",
                                                   "check_what": "omega / theta / phi bit-identical to the K3 launches of the same mode (all 128 "
                                                                 "structures); CA-CA distance and mask planes of 4 structures vs the formula"}

@@ -99,6 +99,14 @@ constexpr bool K3_FLAT_NC4(int NP, int SRC) { return true; }
 // threads of a full-width sweep workgroup: four waves per SIMD with 128 VGPRs each -- two with 256 for the faithful chains at
 // four columns per lane (the library-order chains keep ~2x the values live)
 constexpr int k3_sweep_threads(int NC, bool FAITHFUL) { return FAITHFUL && NC == 4 ? 512 : 1024; }
+#ifdef PS_K3_AB
+// tools only (tools/k3f_probe.py): 2 = every K3 / featuriser kernel computes but stores out of range (the arithmetic and the store
+// issue alone); 1 = k3_featurise_tiles stores constants instead of computing (the store pattern alone)
+__device__ int k3f_probe;
+#define K3_PROBE_RECORDS(n) (k3f_probe == 2 ? 0u : (unsigned)(n))
+#else
+#define K3_PROBE_RECORDS(n) (n)
+#endif
 constexpr size_t K3_LDS_MAX = 160 * 1024 - 256;   // the most dynamic LDS a workgroup of the sweep kernels asks for
 constexpr size_t K3_LDS_ONE_PER_CU = 80 * 1024;   // with its few static bytes on top, two such workgroups do not fit a CU
 constexpr size_t K3_LDS_TWO_PER_CU = 80 * 1024 - 256;   // exactly two such workgroups fit a CU (three would need 240 KB)
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
             const k3_f32x4* slot = k3_flatbuf + (size_t)(b - bs) * slot_vec4;
             const k3_f32x4* rowp = slot + col_vec4;
             float* obase = out + ((size_t)b * out_rows + (size_t)(row_begin - out_row_origin)) * N;
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, rows * N * 4, 0x00020000u);   // this structure's rows, exactly
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)K3_PROBE_RECORDS(rows * N * 4), 0x00020000u);   // this structure's rows, exactly
             if constexpr (MAP == 2) {
                 // TILE map: a lane's element is a 2 x 2 tile -- two row pairs x two adjacent columns, four chains -- so that what
                 // depends on the row pair alone is shared by the tile's two columns and what depends on the column alone by its two
@@ -548,8 +556,13 @@ _Pragma("unroll")                                                               
 // barrier, after the wave's first task, after its last task (tools/k3_stamps.py; DESIGN.md section 4, "where K3's time goes")
 __device__ unsigned long long k3_stamps[512 * 16 * 4];
 #define K3_STAMP(slot) if (lane == 0 && blockIdx.x < 512) k3_stamps[((size_t)blockIdx.x * 16 + wave) * 4 + (slot)] = wall_clock64()
+// ... and of the last k3_featurise_tiles launch: entry, then per staging pass (the first five): pass begun (after the top
+// barrier), rows staged (after the second barrier), this wave's last task of the pass done (tools/k3f_stamps.py)
+__device__ unsigned long long k3f_stamps[512 * 8 * 16];
+#define K3F_STAMP(slot) if (lane == 0 && blockIdx.x < 512 && (slot) < 16) k3f_stamps[((size_t)blockIdx.x * 8 + wave) * 16 + (slot)] = wall_clock64()
 #else
 #define K3_STAMP(slot)
+#define K3F_STAMP(slot)
 #endif
 
 template <int NP, int SRC, int NC, bool VEC, bool FAITHFUL = false>
@@ -620,7 +633,7 @@ __global__ __launch_bounds__(k3_sweep_threads(NC, FAITHFUL)) void k3_sweep(const
         K3_STAMP(1);
         // the segment's rows as one buffer: uniform base, the lane's constant byte offset, the row's byte offset as a scalar
         float* obase = out + ((size_t)b * out_rows + (size_t)(r_lo - out_row_origin)) * N;
-        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, 0xFFFFFFFFu, 0x00020000u);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, K3_PROBE_RECORDS(0xFFFFFFFFu), 0x00020000u);
         const int lane_off = j0 * 4;
         auto rows = [&](int r, f3v (&p)[NP]) {                    // r = row pair index inside the segment
             int q = 0;
@@ -894,7 +907,7 @@ __global__ __launch_bounds__((NC == 4 || FAITHFUL) ? 512 : 1024) void k3_featuri
             constexpr int r_lo = 0;
             const int r_hi = N;
             const size_t seg = (size_t)b * N * N, sbase = seg;
-            auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, 0xFFFFFFFFu, 0x00020000u); };
+            auto rs = [&](void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, K3_PROBE_RECORDS(0xFFFFFFFFu), 0x00020000u); };
             const __amdgpu_buffer_rsrc_t r_dca = rs(d_ca + seg), r_dcb = rs(d_cb + seg), r_dno = rs(d_no + seg), r_om = rs(omega + seg),
                                          r_th = rs(theta + seg), r_ph = rs(phi + seg);
             const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + sbase), r_mcb = rs(m_cb + sbase), r_mno = rs(m_no + sbase);
@@ -1180,9 +1193,12 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
     const int col_vec4 = 3 * N, row_vec4 = 6 * n_rp;
     const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
     const unsigned b_first = t0 / tps, b_last = (t1 - 1u) / tps;
-    for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS) {
+    K3F_STAMP(0);
+    [[maybe_unused]] int pass = 0;
+    for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS, ++pass) {
         const unsigned ks = min((unsigned)KS, b_last - bs + 1u);
         __syncthreads();                                          // the previous pass's readers are done
+        K3F_STAMP(1 + 3 * pass);
         for (unsigned it = threadIdx.x; it < ks * (unsigned)N; it += blockDim.x) {   // one residue of one structure per thread
             unsigned sidx = __umulhi(it, rcpN), r = it - sidx * (unsigned)N;
             if (r >= (unsigned)N) ++sidx, r -= (unsigned)N;
@@ -1207,6 +1223,7 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
         const unsigned seg_t0 = max(t0, bs * tps), seg_t1 = min(t1, (bs + ks) * tps);
         if (threadIdx.x == 0) next_task = seg_t0 + n_waves;       // the first n_waves tasks are pre-assigned
         __syncthreads();
+        K3F_STAMP(2 + 3 * pass);
         unsigned t = seg_t0 + (unsigned)wave;
         while (t < seg_t1) {
             const unsigned b = t / tps, chunk = t - b * tps;      // (uniform)
@@ -1220,7 +1237,11 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
                                          r_om = rs(omega + sbase, fbytes), r_th = rs(theta + sbase, fbytes), r_ph = rs(phi + sbase, fbytes);
             const __amdgpu_buffer_rsrc_t r_mca = rs(m_ca + sbase, mbytes), r_mcb = rs(m_cb + sbase, mbytes), r_mno = rs(m_no + sbase, mbytes);
             const unsigned ti = chunk * 64u + (unsigned)lane;
+#ifdef PS_K3_AB
+            const bool lt = ti < FT && k3f_probe != 2;
+#else
             const bool lt = ti < FT;
+#endif
             const unsigned tcl = min(ti, FT - 1u);
             unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
             if (tc >= TC) ++tr, tc -= TC;
@@ -1298,6 +1319,13 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
                 plane(r_mno, 0u, 2u);      // N_i & O_j
             }
             f32x2 v[4];
+#ifdef PS_K3_AB
+            const int probe = k3f_probe;
+            if (probe == 1) {
+                for (int c = 0; c < 4; ++c) v[c] = f32x2{(float)lane, (float)c};
+                emit(r_dca, v); emit(r_dcb, v); emit(r_dno, v); emit(r_ph, v); emit(r_om, v); emit(r_th, v);
+            } else {
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(CAV[c], CAJ[c]);
             emit(r_dca, v);
@@ -1316,10 +1344,14 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
             if constexpr (FAITHFUL) dihedral4v_ref_n<4>(NV, CAV, CBV, CBJ, v);
             else dihedral4v_k3_n<4>(NV, CAV, CBV, CBJ, v);
             emit(r_th, v);
+#ifdef PS_K3_AB
+            }
+#endif
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
             t = (unsigned)__builtin_amdgcn_readfirstlane((int)nx);
         }
+        K3F_STAMP(3 + 3 * pass);
     }
 }
 
@@ -1474,6 +1506,7 @@ constexpr int K3_FEATURISE_MIN_N = 40;
 constexpr int K3F_TILES_MIN_N = 8, K3F_TILES_MAX_N = 96;     // every chain of 8 .. 96 residues ...
 constexpr int K3F_TILES_MAX_N_EVEN = 200, K3F_TILES_UTIL_PERCENT = 85;   // ... and even lengths up to 200 where < 85 % of the sweep's lanes would have a column
 constexpr unsigned K3F_TILES_WGS = 2;                        // (2 / 3 / 4 workgroups per CU: no difference beyond noise)
+constexpr unsigned K3F_TILES_OVER = 1;                       // workgroups per resident slot
 constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
 constexpr int K3_FLAT_MAX_N = 256;        // ... up to this length (above it the fast sweeps are level with the tiles: 57-64 / 59-66 / 38-42 us)
 constexpr int K3_FLAT_MAX_N_FAITHFUL = 480;   // (faithful: N = 300 94 / 84 / 60 us against 117 / 97 / 66; from 500 on the sweeps win)
@@ -1714,12 +1747,13 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
             if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
 #ifdef PS_K3_AB
             static const unsigned tiles_wgs = getenv("PS_K3F_TILES_WGS") ? (unsigned)atoi(getenv("PS_K3F_TILES_WGS")) : K3F_TILES_WGS;
+            static const unsigned tiles_over = getenv("PS_K3F_TILES_OVER") ? (unsigned)atoi(getenv("PS_K3F_TILES_OVER")) : K3F_TILES_OVER;
 #else
-            constexpr unsigned tiles_wgs = K3F_TILES_WGS;
+            constexpr unsigned tiles_wgs = K3F_TILES_WGS, tiles_over = K3F_TILES_OVER;
 #endif
             // K3F_TILES_WGS 256-thread workgroups per CU (their LDS requests admit exactly that many; 132 / 167 VGPRs: three waves per SIMD)
             const size_t tiles_lds = tiles_wgs == 2 ? K3_LDS_TWO_PER_CU : ((size_t)160 * 1024 / tiles_wgs - 256) & ~(size_t)255;
-            const unsigned slots = (unsigned)go.cus * tiles_wgs;
+            const unsigned slots = (unsigned)go.cus * tiles_wgs * tiles_over;
             const unsigned tasks_per_wg = (unsigned)std::max<unsigned long long>((n_tasks + slots - 1) / slots, 4ull);
             const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
             const unsigned share = (tasks_per_wg + tps - 1) / tps + 1;
@@ -1887,5 +1921,12 @@ extern "C" int ps_featuriser_plan_f32(int B, int N, int A, int float_misalign, i
 extern "C" int ps_k3_debug_stamps(unsigned long long* host_dst, int n_words) {
     if (!host_dst || n_words <= 0 || n_words > 512 * 16 * 4) return (int)hipErrorInvalidValue;
     return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k3_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int ps_k3f_debug_probe(int mode) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(k3f_probe), &mode, sizeof mode, 0, hipMemcpyHostToDevice);
+}
+extern "C" int ps_k3f_debug_stamps(unsigned long long* host_dst, int n_words) {
+    if (!host_dst || n_words <= 0 || n_words > 512 * 8 * 16) return (int)hipErrorInvalidValue;
+    return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(k3f_stamps), (size_t)n_words * 8, 0, hipMemcpyDeviceToHost);
 }
 #endif
