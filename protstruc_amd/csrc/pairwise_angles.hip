@@ -21,7 +21,8 @@
 //                        element is a 2 x 2 tile (row pairs x columns), several structures staged per pass
 //   k3_sweep             >= 100 residues: one workgroup per CU, rows staged in LDS, tasks
 //                        pulled from an LDS counter, NC column residues per lane
-//   k3_inter_residue_geometry, k3_featurise   the fused featuriser: one-column / sweep
+//   k3_inter_residue_geometry, k3_featurise, k3_featurise_tiles   the fused featuriser: one-column / sweep /
+//                        the tile map of k3_flat over all nine planes (8..96 residues and where a sweep would idle lanes)
 #include "ps_common.hpp"
 #include "../../include/protstruc_hip.h"
 
@@ -94,8 +95,6 @@ constexpr bool K3_FEATURISE_NC4 = true;           // four columns per lane: 512-
 // nothing spilled: tools/kernel_resources.sh; same-box A/B at config 3 against two columns at 1024 threads: 80 / 66 / 43 us against
 // 83 / 74 / 48, profiles/r05_k3_modes_first.log)
 constexpr bool K3_FAITHFUL_NC4(int, int) { return true; }
-// the fast flat kernel at four elements per lane where the instantiation keeps its registers (128 VGPRs at 1024 threads)
-constexpr bool K3_FLAT_NC4(int NP, int SRC) { return true; }
 // threads of a full-width sweep workgroup: four waves per SIMD with 128 VGPRs each -- two with 256 for the faithful chains at
 // four columns per lane (the library-order chains keep ~2x the values live)
 constexpr int k3_sweep_threads(int NC, bool FAITHFUL) { return FAITHFUL && NC == 4 ? 512 : 1024; }
@@ -243,23 +242,20 @@ __global__ __launch_bounds__(256) void k3_small(const float* __restrict__ xyz, f
 //   * both sides of a pair come from LDS per lane (lanes of one row pair read the same address: a broadcast);
 //   * tasks are pulled from an LDS counter, as in the sweep; stores are unconditional (a dead element's offset lies beyond the
 //     buffer descriptor's range and the hardware drops it), so the four chains stay in one basic block and interleave.
-// Lane maps (MAP).  2, the product's: a lane's element is a 2 x 2 TILE -- two row pairs x two adjacent columns, four chains --
-// so that what depends on the row pair alone is shared by the tile's two columns and what depends on the column alone by
-// its two row pairs (as in the sweep), the index arithmetic is paid once per tile and two columns are one 8-byte store:
-// ~300 VALU instructions per 8 pairs, 57-64 us per 2^25 pairs from 64 to 220 residues.  0 and 1 (tools only, -DPS_K3_AB): NC
-// elements 64 apart in the flat index (row pair, column) -- 408 instructions per 8 pairs, 68-77 us -- and a lane per column
-// with NC consecutive row pairs (N <= 64: 324 instructions, 69 us at N = 64); profiles/r05_k3_flat_lane_maps.log.  Also tried:
-// a plain coalesced copy of the coordinates instead of the gather of the selected atoms (88 us: it reads all 15 atoms), one
-// 1024-thread workgroup staging its whole share at once (74 us) -- NOTES.md.
+// Lane map: a lane's element is a 2 x 2 TILE -- two row pairs x two adjacent columns, four chains -- so that what depends on
+// the row pair alone is shared by the tile's two columns and what depends on the column alone by its two row pairs (as in the
+// sweep), the index arithmetic is paid once per tile and two columns are one 8-byte store: ~300 VALU instructions per 8 pairs,
+// 57-64 us per 2^25 pairs from 64 to 220 residues.  Measured and removed (profiles/r05_k3_flat_lane_maps.log, NOTES.md): four
+// elements 64 apart in the flat index (408 instructions per 8 pairs, 68-77 us), a lane per column with four consecutive row
+// pairs (N <= 64: 324 instructions, 69 us at N = 64), a plain coalesced copy of the coordinates instead of the gather of the
+// selected atoms (88 us: it reads all 15 atoms), one 1024-thread workgroup staging its whole share at once (74 us).
 // Same arithmetic per pair as the one-column kernel: same bits.
-template <int NP, int SRC, int NC, bool FAITHFUL, int MAP>
+template <int NP, int SRC, bool FAITHFUL>
 __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, float* __restrict__ out, int N, int A,
                                                 AtomSel sel, int row_begin, int row_end, int out_rows,
                                                 int out_row_origin, int KS, unsigned tps, unsigned n_tasks,
                                                 unsigned tasks_per_wg, unsigned rcpN, int col_vec4, int slot_vec4,
                                                 unsigned rcpTC, int vec2) {
-    constexpr bool ROWMAJOR = MAP == 1;
-    static_assert(NC == 2 || NC == 4, "elements per lane");
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     constexpr int NPIq = NPI > 0 ? NPI : 1, NPJq = NPJ > 0 ? NPJ : 1;
     // [structure slot][column part: (atom, residue) -> {x, y, z, -} | row part: (row pair, atom) -> {x0, x1, y0, y1}, {z0, z1, -, -}]
@@ -282,7 +278,6 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
         if (NPJ == 0) amap_j[0] = 0;
     }
     const int rows = row_end - row_begin, n_rp = (rows + 1) >> 1;
-    const unsigned F = (unsigned)n_rp * (unsigned)N;   // flat elements (row pair, column) of one structure
     const unsigned b_first = t0 / tps, b_last = (t1 - 1u) / tps;
     for (unsigned bs = b_first; bs <= b_last; bs += (unsigned)KS) {
         const unsigned ks = min((unsigned)KS, b_last - bs + 1u);
@@ -319,142 +314,66 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
             const k3_f32x4* rowp = slot + col_vec4;
             float* obase = out + ((size_t)b * out_rows + (size_t)(row_begin - out_row_origin)) * N;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)K3_PROBE_RECORDS(rows * N * 4), 0x00020000u);   // this structure's rows, exactly
-            if constexpr (MAP == 2) {
-                // TILE map: a lane's element is a 2 x 2 tile -- two row pairs x two adjacent columns, four chains -- so that what
-                // depends on the row pair alone is shared by the tile's two columns and what depends on the column alone by its two
-                // row pairs (as in the sweep), the index arithmetic is paid once per tile, and two adjacent columns are one 8-byte store
-                const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
-                const unsigned ti = chunk * 64u + (unsigned)lane;
-                const bool lt = ti < FT;
-                const unsigned tcl = min(ti, FT - 1u);
-                unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
-                if (tc >= TC) ++tr, tc -= TC;
-                const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
-                const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
-                const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
-                f3v P[NP][4];
-                {
-                    int qi = 0, qj = 0;
+            // the lane's tile: two row pairs x two adjacent columns
+            const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
+            const unsigned ti = chunk * 64u + (unsigned)lane;
+            const bool lt = ti < FT;
+            const unsigned tcl = min(ti, FT - 1u);
+            unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
+            if (tc >= TC) ++tr, tc -= TC;
+            const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
+            const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
+            const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
+            f3v P[NP][4];
+            {
+                int qi = 0, qj = 0;
 #pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        if ((SRC >> k) & 1) {
-                            const k3_f32x4 p0 = slot[qj * N + c0], p1 = slot[qj * N + c1];
-                            P[k][0] = P[k][2] = mk3v(f3{p0.x, p0.y, p0.z}, f3{p0.x, p0.y, p0.z});
-                            P[k][1] = P[k][3] = mk3v(f3{p1.x, p1.y, p1.z}, f3{p1.x, p1.y, p1.z});
-                            ++qj;
-                        } else {
-                            const k3_f32x4 xa = rowp[(rpA * NPI + qi) * 2], xb = rowp[(rpB * NPI + qi) * 2];
-                            const f32x2 za = *reinterpret_cast<const f32x2*>(rowp + (rpA * NPI + qi) * 2 + 1);
-                            const f32x2 zb = *reinterpret_cast<const f32x2*>(rowp + (rpB * NPI + qi) * 2 + 1);
-                            P[k][0] = P[k][1] = f3v{f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, za};
-                            P[k][2] = P[k][3] = f3v{f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}, zb};
-                            ++qi;
-                        }
-                    }
-                }
-                f32x2 v[4];
-                if constexpr (NP == 4 && FAITHFUL)
-                    dihedral4v_ref_n<4>(P[0], P[1], P[2], P[3], v);
-                else if constexpr (NP == 4)
-                    dihedral4v_k3_n<4>(P[0], P[1], P[2], P[3], v);
-                else if constexpr (FAITHFUL)
-                    angle3v_ref_n<4>(P[0], P[1], P[2], v);
-                else
-                    angle3v_n<4>(P[0], P[1], P[2], v);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
-                const int offA = (int)__umul24((unsigned)(2 * rpA), (unsigned)N) * 4 + c0 * 4;
-                const int offB = (int)__umul24((unsigned)(2 * rpB), (unsigned)N) * 4 + c0 * 4;
-                const bool rA1 = 2 * rpA + 1 < rows, rB0 = lrB, rB1 = lrB && 2 * rpB + 1 < rows;   // rows 2 rpA + 1, 2 rpB, 2 rpB + 1 exist
-                constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
-                if (vec2) {      // (uniform) N even and the rows 8-byte aligned: the tile's two columns are one store
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lt ? offA : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].y, v[3].y}), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
-                } else {
-                    const bool l1 = lt && lc1;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].x), rsrc, lt ? offA : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].x), rsrc, l1 ? offA + 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].y), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].y), rsrc, (l1 && rA1) ? offA + N * 4 + 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].x), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].x), rsrc, (l1 && rB0) ? offB + 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].y), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].y), rsrc, (l1 && rB1) ? offB + N * 4 + 4 : DEAD, 0, 0);
-                }
-            } else {
-            // ROWMAJOR (N <= 64): the lane is column `lane` and its NC elements are NC consecutive row pairs -- no per-lane index
-            // arithmetic at all, the row side is one uniform address per element and what depends on the column alone is
-            // shared by the NC chains.  Otherwise: NC elements 64 apart in the flat index
-            const unsigned f0 = ROWMAJOR ? chunk * (unsigned)NC * (unsigned)N : chunk * (unsigned)(64 * NC);
-            // the task's first element on the scalar unit; a lane's elements follow by at most two wraps per 64 (N >= 32)
-            const unsigned rp0 = ROWMAJOR ? chunk * (unsigned)NC : f0 / (unsigned)N, j0 = ROWMAJOR ? 0u : f0 - rp0 * (unsigned)N;
-            auto run = [&](auto l_tag) {
-                constexpr int L = decltype(l_tag)::value;
-                f3v P[NP][L];
-                int off[L];
-                bool live[L], two[L];
-                int j = ROWMAJOR ? min(lane, N - 1) : (int)j0 + lane, rp = (int)rp0;
-#pragma unroll
-                for (int c = 0; c < L; ++c) {
-                    if constexpr (ROWMAJOR) {
-                        rp = (int)rp0 + c;
-                        live[c] = lane < N && rp < n_rp;
+                for (int k = 0; k < NP; ++k) {
+                    if ((SRC >> k) & 1) {
+                        const k3_f32x4 p0 = slot[qj * N + c0], p1 = slot[qj * N + c1];
+                        P[k][0] = P[k][2] = mk3v(f3{p0.x, p0.y, p0.z}, f3{p0.x, p0.y, p0.z});
+                        P[k][1] = P[k][3] = mk3v(f3{p1.x, p1.y, p1.z}, f3{p1.x, p1.y, p1.z});
+                        ++qj;
                     } else {
-                        if (c > 0) j += 64;
-#pragma unroll
-                        for (int w = 0; w < 2; ++w) {
-                            const bool wrap = j >= N;
-                            j = wrap ? j - N : j;
-                            rp = wrap ? rp + 1 : rp;
-                        }
-                        live[c] = f0 + (unsigned)(c * 64 + lane) < F;
-                    }
-                    const int rpc = min(rp, n_rp - 1);            // dead elements read a live address and store nothing
-                    off[c] = (int)__umul24((unsigned)(2 * rpc), (unsigned)N) * 4 + j * 4;
-                    two[c] = 2 * rpc + 1 < rows;
-                    int qi = 0, qj = 0;
-#pragma unroll
-                    for (int k = 0; k < NP; ++k) {
-                        if ((SRC >> k) & 1) {
-                            const k3_f32x4 pj = slot[qj * N + j];
-                            P[k][c] = mk3v(f3{pj.x, pj.y, pj.z}, f3{pj.x, pj.y, pj.z});
-                            ++qj;
-                        } else {
-                            const k3_f32x4 xy = rowp[(rpc * NPI + qi) * 2];
-                            const f32x2 z = *reinterpret_cast<const f32x2*>(rowp + (rpc * NPI + qi) * 2 + 1);
-                            P[k][c] = f3v{f32x2{xy.x, xy.y}, f32x2{xy.z, xy.w}, z};
-                            ++qi;
-                        }
+                        const k3_f32x4 xa = rowp[(rpA * NPI + qi) * 2], xb = rowp[(rpB * NPI + qi) * 2];
+                        const f32x2 za = *reinterpret_cast<const f32x2*>(rowp + (rpA * NPI + qi) * 2 + 1);
+                        const f32x2 zb = *reinterpret_cast<const f32x2*>(rowp + (rpB * NPI + qi) * 2 + 1);
+                        P[k][0] = P[k][1] = f3v{f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, za};
+                        P[k][2] = P[k][3] = f3v{f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}, zb};
+                        ++qi;
                     }
                 }
-                f32x2 v[L];
-                if constexpr (NP == 4 && FAITHFUL)
-                    dihedral4v_ref_n<L>(P[0], P[1], P[2], P[3], v);
-                else if constexpr (NP == 4)
-                    dihedral4v_k3_n<L>(P[0], P[1], P[2], P[3], v);
-                else if constexpr (FAITHFUL)
-                    angle3v_ref_n<L>(P[0], P[1], P[2], v);
-                else
-                    angle3v_n<L>(P[0], P[1], P[2], v);
-                // results pinned before the stores (or the compiler sinks each chain into its own store's branch and the chains no
-                // longer interleave); the stores themselves are unconditional: a dead element's offset lies beyond the buffer's
-                // num_records and the hardware range check drops it
+            }
+            f32x2 v[4];
+            if constexpr (NP == 4 && FAITHFUL)
+                dihedral4v_ref_n<4>(P[0], P[1], P[2], P[3], v);
+            else if constexpr (NP == 4)
+                dihedral4v_k3_n<4>(P[0], P[1], P[2], P[3], v);
+            else if constexpr (FAITHFUL)
+                angle3v_ref_n<4>(P[0], P[1], P[2], v);
+            else
+                angle3v_n<4>(P[0], P[1], P[2], v);
 #pragma unroll
-                for (int c = 0; c < L; ++c) asm volatile("" : "+v"(v[c]));
-#pragma unroll
-                for (int c = 0; c < L; ++c) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c].x), rsrc, live[c] ? off[c] : 0x7FFFFFF0, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[c].y), rsrc, (live[c] && two[c]) ? off[c] + N * 4 : 0x7FFFFFF0, 0, 0);
-                }
-            };
-            // live elements per lane of this task (uniform; > 0): 64-element groups, or row pairs
-            const unsigned ngr = ROWMAJOR ? (unsigned)n_rp - rp0 : (F - f0 + 63u) >> 6;
-            if (ngr >= (unsigned)NC) run(std::integral_constant<int, NC>{});
-            else if (NC == 4 && ngr == 3u) run(std::integral_constant<int, NC == 4 ? 3 : 1>{});
-            else if (NC == 4 && ngr == 2u) run(std::integral_constant<int, NC == 4 ? 2 : 1>{});
-            else run(std::integral_constant<int, 1>{});
+            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
+            const int offA = (int)__umul24((unsigned)(2 * rpA), (unsigned)N) * 4 + c0 * 4;
+            const int offB = (int)__umul24((unsigned)(2 * rpB), (unsigned)N) * 4 + c0 * 4;
+            const bool rA1 = 2 * rpA + 1 < rows, rB0 = lrB, rB1 = lrB && 2 * rpB + 1 < rows;   // rows 2 rpA + 1, 2 rpB, 2 rpB + 1 exist
+            constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
+            if (vec2) {      // (uniform) N even and the rows 8-byte aligned: the tile's two columns are one store
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lt ? offA : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].y, v[3].y}), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
+            } else {
+                const bool l1 = lt && lc1;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].x), rsrc, lt ? offA : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].x), rsrc, l1 ? offA + 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0].y), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[1].y), rsrc, (l1 && rA1) ? offA + N * 4 + 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].x), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].x), rsrc, (l1 && rB0) ? offB + 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[2].y), rsrc, (lt && rB1) ? offB + N * 4 : DEAD, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[3].y), rsrc, (l1 && rB1) ? offB + N * 4 + 4 : DEAD, 0, 0);
             }
             unsigned nx = 0;
             if (lane == 0) nx = atomicAdd(&next_task, 1u);
@@ -1437,16 +1356,13 @@ int launch_sweep(const float* xyz, float* out, int B, int N, int A, const AtomSe
 // LDS the flat kernel stages its structures in (one workgroup per CU: the request keeps a second one off the CU)
 constexpr size_t K3_FLAT_LDS = 128 * 1024;
 
-template <int NP, int SRC, int NC, bool FAITHFUL, int MAP>
+template <int NP, int SRC, bool FAITHFUL>
 int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel, int row_begin, int row_end, int out_rows,
                 int out_row_origin, unsigned out_misalign_bytes, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     const int rows = row_end - row_begin, rp = (rows + 1) / 2;
-    const unsigned long long F = (unsigned long long)rp * N;
-    // tasks per structure: NC elements per lane -- 64 apart in the flat index, or (ROWMAJOR) NC row pairs of the lane's column
-    constexpr bool ROWMAJOR = MAP == 1;
-    const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(rp + 1) / 2;      // MAP == 2: tiles of two row pairs x two columns
-    const unsigned tps = MAP == 2 ? (TR * TC + 63u) / 64u : ROWMAJOR ? (unsigned)((rp + NC - 1) / NC) : (unsigned)((F + 64 * NC - 1) / (64 * NC));
+    const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(rp + 1) / 2;      // tiles of two row pairs x two columns
+    const unsigned tps = (TR * TC + 63u) / 64u;                                   // tasks (64 tiles) per structure
     const unsigned long long n_tasks = (unsigned long long)tps * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
     const int col_vec4 = NPJ * N, slot_vec4 = col_vec4 + rp * NPI * 2;   // 16-byte units: {x, y, z, -} per column atom; two per row-pair atom
@@ -1470,14 +1386,14 @@ int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel
     const size_t dyn = wgs == 2 ? K3_LDS_TWO_PER_CU : std::max((size_t)KS * slot_vec4 * 16, K3_LDS_ONE_PER_CU);
     static unsigned long long prepared[1] = {0};
     char name[96];
-    snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,NC=%d,FAITHFUL=%d,MAP=%d>", NP, SRC, NC, (int)FAITHFUL, MAP);
-    // MAP == 2: two adjacent columns as one 8-byte store where the rows allow it
-    const int vec2 = MAP == 2 && N % 2 == 0 && ((out_misalign_bytes + (unsigned)(((long long)row_begin - out_row_origin) * N * 4)) & 7u) == 0;
+    snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,FAITHFUL=%d>", NP, SRC, (int)FAITHFUL);
+    // the tile's two adjacent columns as one 8-byte store where the rows allow it
+    const int vec2 = N % 2 == 0 && ((out_misalign_bytes + (unsigned)(((long long)row_begin - out_row_origin) * N * 4)) & 7u) == 0;
     K3Shape sh;
-    sh.nc = NC; sh.skips = 1; sh.faithful = FAITHFUL; sh.rows_per_task = ROWMAJOR ? 2 * NC : 0; sh.wgs_per_cu = wgs; sh.structs_per_segment = KS;
+    sh.nc = 4; sh.skips = 1; sh.faithful = FAITHFUL; sh.rows_per_task = 0; sh.wgs_per_cu = wgs; sh.structs_per_segment = KS;
     sh.vec = vec2;
     sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
-    return k3_go(go, MAP == 2 ? "flat_tiles" : ROWMAJOR ? "flat_rows" : "flat", name, sh, k3_flat<NP, SRC, NC, FAITHFUL, MAP>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
+    return k3_go(go, "flat_tiles", name, sh, k3_flat<NP, SRC, FAITHFUL>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
                  row_end, out_rows, out_row_origin, KS, tps, (unsigned)n_tasks, tasks_per_wg, (unsigned)((1ull << 32) / (unsigned)N), col_vec4,
                  slot_vec4, (unsigned)((1ull << 32) / std::max(1u, TC)), vec2);
 }
@@ -1507,7 +1423,6 @@ constexpr int K3F_TILES_MIN_N = 8, K3F_TILES_MAX_N = 96;     // every chain of 8
 constexpr int K3F_TILES_MAX_N_EVEN = 200, K3F_TILES_UTIL_PERCENT = 85;   // ... and even lengths up to 200 where < 85 % of the sweep's lanes would have a column
 constexpr unsigned K3F_TILES_WGS = 2;                        // (2 / 3 / 4 workgroups per CU: no difference beyond noise)
 constexpr unsigned K3F_TILES_OVER = 1;                       // workgroups per resident slot
-constexpr int K3_FLAT_ROWS_MIN_N = 57;   // the flat kernel with a lane per column (its elements NC row pairs) from here to 64 residues
 constexpr int K3_FLAT_MAX_N = 256;        // ... up to this length (above it the fast sweeps are level with the tiles: 57-64 / 59-66 / 38-42 us)
 constexpr int K3_FLAT_MAX_N_FAITHFUL = 480;   // (faithful: N = 300 94 / 84 / 60 us against 117 / 97 / 66; from 500 on the sweeps win)
 constexpr int K3_FLAT_UTIL_PERCENT = 95; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
@@ -1566,12 +1481,11 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     static const int force_nc = getenv("PS_K3_NC") ? atoi(getenv("PS_K3_NC")) : 0;
     const bool allow4 = force_nc != 2;
     static const int flat_util = getenv("PS_K3_FLAT_UTIL") ? atoi(getenv("PS_K3_FLAT_UTIL")) : (FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT);
-    static const int rows_min = getenv("PS_K3_ROWMAJOR_MIN") ? atoi(getenv("PS_K3_ROWMAJOR_MIN")) : K3_FLAT_ROWS_MIN_N;
     static const int flat_max_n = getenv("PS_K3_FLAT_MAX_N") ? atoi(getenv("PS_K3_FLAT_MAX_N")) : (FAITHFUL ? K3_FLAT_MAX_N_FAITHFUL : K3_FLAT_MAX_N);
 #else
     constexpr int flat_max_n = FAITHFUL ? K3_FLAT_MAX_N_FAITHFUL : K3_FLAT_MAX_N;
     const bool allow4 = true;
-    constexpr int flat_util = FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT, rows_min = K3_FLAT_ROWS_MIN_N;
+    constexpr int flat_util = FAITHFUL ? K3_FLAT_UTIL_PERCENT_FAITHFUL : K3_FLAT_UTIL_PERCENT;
 #endif
     const bool ok4 = NC4 && allow4 && fits && N % 4 == 0 && (out_misalign & 15u) == 0, ok2 = fits && N % 2 == 0 && (out_misalign & 7u) == 0;
     // lanes past the last column idle: take the width that wastes fewer of them (a tie goes to the wider stores)
@@ -1591,15 +1505,7 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     // 59 against 102 us; N = 180: 59 / 66 / 46 against 61 / 74 / 50).
     if (!simple && N > small_max && N >= 32 && k3_flat_fits(N, A) &&
         (N < K3_SWEEP_MIN_N || !fits || (N <= flat_max_n && (long long)N * 100 < (long long)flat_util * 64 * g_eval))) {
-#ifdef PS_K3_AB
-        static const int flat_map = getenv("PS_K3_FLAT_MAP") ? atoi(getenv("PS_K3_FLAT_MAP")) : 2;
-        if (flat_map == 0 || (flat_map == 1 && !(N >= rows_min && N <= 64)))
-            return launch_flat<NP, SRC, 4, FAITHFUL, 0>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
-        if (flat_map == 1)
-            return launch_flat<NP, SRC, 4, FAITHFUL, 1>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
-#endif
-        (void)rows_min;
-        return launch_flat<NP, SRC, 4, FAITHFUL, 2>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
+        return launch_flat<NP, SRC, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
     }
     if (vec) {
         if constexpr (NC4) {

@@ -1,5 +1,6 @@
 # Round 5: K3 across chain lengths (bash tools/gpu_k3_flat_r05.sh [outdir]): K3 GPU tests; the dispatcher's pick against the one-column
 # kernel at 2^25 pairs per launch, both arithmetic modes (-> profiles/r05_k3_shapes.log).  The flat kernel's three lane maps side by
+# (history: the lane maps 0 and 1 and their PS_K3_FLAT_MAP / PS_K3_ROWMAJOR_MIN switches were removed from the source after this run)
 # side (-DPS_K3_AB build, PS_K3_FLAT_MAP = 0: elements 64 apart, 1: a lane per column at 57..64, 2: 2 x 2 tiles): profiles/r05_k3_flat_lane_maps.log
 set -o pipefail
 O=gpurun_out/${1:-r05flat}
