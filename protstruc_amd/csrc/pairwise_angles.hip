@@ -255,7 +255,7 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
                                                 AtomSel sel, int row_begin, int row_end, int out_rows,
                                                 int out_row_origin, int KS, unsigned tps, unsigned n_tasks,
                                                 unsigned tasks_per_wg, unsigned rcpN, int col_vec4, int slot_vec4,
-                                                unsigned rcpTC, int vec2) {
+                                                unsigned rcpTC, int vec) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     constexpr int NPIq = NPI > 0 ? NPI : 1, NPJq = NPJ > 0 ? NPJ : 1;
     // [structure slot][column part: (atom, residue) -> {x, y, z, -} | row part: (row pair, atom) -> {x0, x1, y0, y1}, {z0, z1, -, -}]
@@ -314,52 +314,76 @@ __global__ __launch_bounds__(1024) void k3_flat(const float* __restrict__ xyz, f
             const k3_f32x4* rowp = slot + col_vec4;
             float* obase = out + ((size_t)b * out_rows + (size_t)(row_begin - out_row_origin)) * N;
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(obase, 0, (int)K3_PROBE_RECORDS(rows * N * 4), 0x00020000u);   // this structure's rows, exactly
-            // the lane's tile: two row pairs x two adjacent columns
-            const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
+            // the lane's tile: two row pairs x two adjacent columns (four chains) -- or, where a row of FOUR columns is one aligned
+            // 16-byte store (vec == 4: N % 4 == 0), two such halves that share the index arithmetic and the row-side points
+            // (N = 64 .. 220: 58-65 / 60-66 / 43-50 us per 2^25 pairs against 62-73 / 68-79 / 48-59; without the wide store the
+            // four-column tile loses: N = 99 76 against 70 us, N = 33 148 against 129; profiles/r05_k3_flat_tile_width.log)
+            const bool wide = vec == 4;                      // (uniform)
+            const unsigned TC = wide ? (unsigned)N >> 2 : (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
             const unsigned ti = chunk * 64u + (unsigned)lane;
             const bool lt = ti < FT;
             const unsigned tcl = min(ti, FT - 1u);
             unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
             if (tc >= TC) ++tr, tc -= TC;
-            const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
+            const int c0 = (int)(wide ? 4u * tc : 2u * tc);
             const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
             const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
-            f3v P[NP][4];
-            {
+            f3v RA[NPIq], RB[NPIq];                   // the row-side points of the two row pairs ({row 2 rp, row 2 rp + 1} per component)
+#pragma unroll
+            for (int qi = 0; qi < NPI; ++qi) {
+                const k3_f32x4 xa = rowp[(rpA * NPI + qi) * 2], xb = rowp[(rpB * NPI + qi) * 2];
+                const f32x2 za = *reinterpret_cast<const f32x2*>(rowp + (rpA * NPI + qi) * 2 + 1);
+                const f32x2 zb = *reinterpret_cast<const f32x2*>(rowp + (rpB * NPI + qi) * 2 + 1);
+                RA[qi] = f3v{f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, za};
+                RB[qi] = f3v{f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}, zb};
+            }
+            // columns ca, ca + 1 (clamped: a dead column is never stored) against the two row pairs:
+            // v[0], v[1] = row pair A x the two columns; v[2], v[3] = row pair B; .x / .y = the pair's rows
+            auto half = [&](int ca, f32x2 (&v)[4]) {
+                const int cb = min(ca + 1, N - 1);
+                f3v P[NP][4];
                 int qi = 0, qj = 0;
 #pragma unroll
                 for (int k = 0; k < NP; ++k) {
                     if ((SRC >> k) & 1) {
-                        const k3_f32x4 p0 = slot[qj * N + c0], p1 = slot[qj * N + c1];
+                        const k3_f32x4 p0 = slot[qj * N + ca], p1 = slot[qj * N + cb];
                         P[k][0] = P[k][2] = mk3v(f3{p0.x, p0.y, p0.z}, f3{p0.x, p0.y, p0.z});
                         P[k][1] = P[k][3] = mk3v(f3{p1.x, p1.y, p1.z}, f3{p1.x, p1.y, p1.z});
                         ++qj;
                     } else {
-                        const k3_f32x4 xa = rowp[(rpA * NPI + qi) * 2], xb = rowp[(rpB * NPI + qi) * 2];
-                        const f32x2 za = *reinterpret_cast<const f32x2*>(rowp + (rpA * NPI + qi) * 2 + 1);
-                        const f32x2 zb = *reinterpret_cast<const f32x2*>(rowp + (rpB * NPI + qi) * 2 + 1);
-                        P[k][0] = P[k][1] = f3v{f32x2{xa.x, xa.y}, f32x2{xa.z, xa.w}, za};
-                        P[k][2] = P[k][3] = f3v{f32x2{xb.x, xb.y}, f32x2{xb.z, xb.w}, zb};
+                        P[k][0] = P[k][1] = RA[qi];
+                        P[k][2] = P[k][3] = RB[qi];
                         ++qi;
                     }
                 }
-            }
-            f32x2 v[4];
-            if constexpr (NP == 4 && FAITHFUL)
-                dihedral4v_ref_n<4>(P[0], P[1], P[2], P[3], v);
-            else if constexpr (NP == 4)
-                dihedral4v_k3_n<4>(P[0], P[1], P[2], P[3], v);
-            else if constexpr (FAITHFUL)
-                angle3v_ref_n<4>(P[0], P[1], P[2], v);
-            else
-                angle3v_n<4>(P[0], P[1], P[2], v);
+                if constexpr (NP == 4 && FAITHFUL)
+                    dihedral4v_ref_n<4>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (NP == 4)
+                    dihedral4v_k3_n<4>(P[0], P[1], P[2], P[3], v);
+                else if constexpr (FAITHFUL)
+                    angle3v_ref_n<4>(P[0], P[1], P[2], v);
+                else
+                    angle3v_n<4>(P[0], P[1], P[2], v);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
+                for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
+            };
+            f32x2 v[4];
+            half(c0, v);
             const int offA = (int)__umul24((unsigned)(2 * rpA), (unsigned)N) * 4 + c0 * 4;
             const int offB = (int)__umul24((unsigned)(2 * rpB), (unsigned)N) * 4 + c0 * 4;
             const bool rA1 = 2 * rpA + 1 < rows, rB0 = lrB, rB1 = lrB && 2 * rpB + 1 < rows;   // rows 2 rpA + 1, 2 rpB, 2 rpB + 1 exist
             constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
-            if (vec2) {      // (uniform) N even and the rows 8-byte aligned: the tile's two columns are one store
+            if (wide) {              // N % 4 == 0 and the rows 16-byte aligned: a row of the tile is one store
+                f32x2 w[4];
+                half(c0 + 2, w);     // (c0 + 3 < N)
+                auto st4 = [&](float a, float b, float c, float d, int off) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{a, b, c, d}), rsrc, off, 0, 0);
+                };
+                st4(v[0].x, v[1].x, w[0].x, w[1].x, lt ? offA : DEAD);
+                st4(v[0].y, v[1].y, w[0].y, w[1].y, (lt && rA1) ? offA + N * 4 : DEAD);
+                st4(v[2].x, v[3].x, w[2].x, w[3].x, (lt && rB0) ? offB : DEAD);
+                st4(v[2].y, v[3].y, w[2].y, w[3].y, (lt && rB1) ? offB + N * 4 : DEAD);
+            } else if (vec == 2) {   // (uniform) N even and the rows 8-byte aligned: the tile's two columns are one store
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rsrc, lt ? offA : DEAD, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rsrc, (lt && rA1) ? offA + N * 4 : DEAD, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rsrc, (lt && rB0) ? offB : DEAD, 0, 0);
@@ -1361,7 +1385,19 @@ int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel
                 int out_row_origin, unsigned out_misalign_bytes, const K3Go& go) {
     constexpr int NPI = NP - __builtin_popcount(SRC & ((1 << NP) - 1)), NPJ = NP - NPI;
     const int rows = row_end - row_begin, rp = (rows + 1) / 2;
-    const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(rp + 1) / 2;      // tiles of two row pairs x two columns
+    // a row of the tile as one 16-byte store (then the tile is four columns wide), or as one 8-byte store, where the chain length
+    // and the rows' alignment allow it
+    const unsigned mis = out_misalign_bytes + (unsigned)(((long long)row_begin - out_row_origin) * N * 4);
+    int vec = (N % 4 == 0 && (mis & 15u) == 0) ? 4 : (N % 2 == 0 && (mis & 7u) == 0) ? 2 : 0;
+    const unsigned TR = (unsigned)(rp + 1) / 2;
+    if (vec == 4) {
+        // a structure's tiles fill whole tasks of 64: the wide tile's instruction saving (~10 %) must not go to idle lanes of the
+        // last task (N = 36: 81 tiles in 2 tasks against 162 in 3: 113 against 105 us; N = 48: 144 in 3 against 288 in 5: level)
+        const unsigned ft_w = TR * ((unsigned)N / 4), ft_n = TR * ((unsigned)N / 2);
+        const unsigned long long lanes_w = 64ull * ((ft_w + 63) / 64) * 2, lanes_n = 64ull * ((ft_n + 63) / 64);   // in narrow-tile units
+        if (lanes_w * 100 > lanes_n * 108) vec = 2;
+    }
+    const unsigned TC = vec == 4 ? (unsigned)N / 4 : (unsigned)(N + 1) / 2;       // tiles of two row pairs x four / two columns
     const unsigned tps = (TR * TC + 63u) / 64u;                                   // tasks (64 tiles) per structure
     const unsigned long long n_tasks = (unsigned long long)tps * B;
     if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
@@ -1387,15 +1423,13 @@ int launch_flat(const float* xyz, float* out, int B, int N, int A, const AtomSel
     static unsigned long long prepared[1] = {0};
     char name[96];
     snprintf(name, sizeof name, "k3_flat<NP=%d,SRC=%d,FAITHFUL=%d>", NP, SRC, (int)FAITHFUL);
-    // the tile's two adjacent columns as one 8-byte store where the rows allow it
-    const int vec2 = N % 2 == 0 && ((out_misalign_bytes + (unsigned)(((long long)row_begin - out_row_origin) * N * 4)) & 7u) == 0;
     K3Shape sh;
     sh.nc = 4; sh.skips = 1; sh.faithful = FAITHFUL; sh.rows_per_task = 0; sh.wgs_per_cu = wgs; sh.structs_per_segment = KS;
-    sh.vec = vec2;
+    sh.vec = vec / 2;                       // ps_k3_plan.vector_stores: 0 dword, 1 8-byte, 2 16-byte stores
     sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
     return k3_go(go, "flat_tiles", name, sh, k3_flat<NP, SRC, FAITHFUL>, &prepared, dim3(grid), dim3(1024 / wgs), dyn, 4u, xyz, out, N, A, sel, row_begin,
                  row_end, out_rows, out_row_origin, KS, tps, (unsigned)n_tasks, tasks_per_wg, (unsigned)((1ull << 32) / (unsigned)N), col_vec4,
-                 slot_vec4, (unsigned)((1ull << 32) / std::max(1u, TC)), vec2);
+                 slot_vec4, (unsigned)((1ull << 32) / std::max(1u, TC)), vec);
 }
 
 // whether one structure's selected atoms fit the flat kernel's LDS (two workgroups per CU)
@@ -1424,6 +1458,8 @@ constexpr int K3F_TILES_MAX_N_EVEN = 200, K3F_TILES_UTIL_PERCENT = 85;   // ... 
 constexpr unsigned K3F_TILES_WGS = 2;                        // (2 / 3 / 4 workgroups per CU: no difference beyond noise)
 constexpr unsigned K3F_TILES_OVER = 1;                       // workgroups per resident slot
 constexpr int K3_FLAT_MAX_N = 256;        // ... up to this length (above it the fast sweeps are level with the tiles: 57-64 / 59-66 / 38-42 us)
+constexpr int K3_FLAT_MAX_N_WIDE = 448;   // ... this one where the tiles are four columns wide (N % 4 == 0, 16-byte rows): 56-59 / 54-61 / 38-44 us from 288 to 448
+                                          // residues against the sweeps' 56-72 / 59-69 / 39-49 (level at 256 and 384; from 480 on the sweeps win)
 constexpr int K3_FLAT_MAX_N_FAITHFUL = 480;   // (faithful: N = 300 94 / 84 / 60 us against 117 / 97 / 66; from 500 on the sweeps win)
 constexpr int K3_FLAT_UTIL_PERCENT = 95; // ... and instead of a sweep of which fewer than this share of the lanes would have a column
 constexpr int K3_FLAT_UTIL_PERCENT_FAITHFUL = 95;   // (the faithful sweeps, two waves per SIMD, lose even more to idle lanes: N = 160 149 us against 98)
@@ -1503,8 +1539,17 @@ int launch(const float* xyz, float* out, int B, int N, int A, const AtomSel& sel
     // 48 to 140 residues, profiles/r05_k3_shapes.log): every chain shorter than the sweeps' minimum, and up to 256 residues wherever
     // fewer than K3_FLAT_UTIL_PERCENT of the sweep's lanes would have a column (N = 140: three groups of 64 for 140 columns,
     // 59 against 102 us; N = 180: 59 / 66 / 46 against 61 / 74 / 50).
+    const bool wide_tiles = N % 4 == 0 && (out_misalign & 15u) == 0;
+#ifdef PS_K3_AB
+    const int flat_max = (getenv("PS_K3_FLAT_MAX_N") || FAITHFUL || !wide_tiles) ? flat_max_n : K3_FLAT_MAX_N_WIDE;
+#else
+    const int flat_max = (FAITHFUL || !wide_tiles) ? flat_max_n : K3_FLAT_MAX_N_WIDE;
+#endif
     if (!simple && N > small_max && N >= 32 && k3_flat_fits(N, A) &&
-        (N < K3_SWEEP_MIN_N || !fits || (N <= flat_max_n && (long long)N * 100 < (long long)flat_util * 64 * g_eval))) {
+        (N < K3_SWEEP_MIN_N || !fits ||
+         (N <= flat_max && ((long long)N * 100 < (long long)flat_util * 64 * g_eval ||
+                              // ... or where the sweep would write dwords (its columns 64 apart) and the tiles whole 16-byte rows: N = 192
+                              (!vec && wide_tiles))))) {
         return launch_flat<NP, SRC, FAITHFUL>(xyz, out, B, N, A, sel, row_begin, row_end, out_rows, out_row_origin, out_misalign, go);
     }
     if (vec) {

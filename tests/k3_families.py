@@ -28,16 +28,19 @@ K3_SHAPES = [
     (3, 16, CA_CB__CA_CB, None, False, 0, 0, arm("small", nc=16), True),
     (5, 20, N_CA_CB__CB, (3, 17), True, 0, 0, arm("small", nc=32), True),
     (2, 32, CA_CB__CB, None, False, 4, 0, arm("small", nc=32), True),
-    (3, 64, CA_CB__CA_CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
+    (3, 64, CA_CB__CA_CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=2, skips=1, wgs=2), True),
     (700, 60, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),   # several staging passes per workgroup
     (5, 57, C__N_CA_C, (4, 31), True, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
     (700, 48, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
     (5, 33, C__N_CA_C, (4, 31), True, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
-    (2, 140, CA_CB__CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),            # three column groups for 140 columns: flat
+    (2, 140, CA_CB__CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=2, skips=1, wgs=2), True),            # three column groups for 140 columns: flat
     (2, 130, CA_CB__CA_CB, (1, 130), False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
     (2, 99, CA_CB__CB, (1, 98), False, 0, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
     (700, 65, N_CA_CB__CB, None, False, 4, 0, arm("flat_tiles", nc=4, vec=0, skips=1, wgs=2), True),
-    (5, 80, C__N_CA_C, (4, 77), True, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),
+    (5, 80, C__N_CA_C, (4, 77), True, 0, 0, arm("flat_tiles", nc=4, vec=2, skips=1, wgs=2), True),
+    (300, 100, CA_CB__CA_CB, (3, 98), False, 0, 0, arm("flat_tiles", nc=4, vec=2, skips=1, wgs=2), True),   # four-column tiles, a row range inside a full-size plane
+    (3, 64, CA_CB__CB, None, False, 8, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),             # N % 4 == 0 but only 8-byte aligned: two-column tiles
+    (900, 36, CA_CB__CA_CB, None, False, 0, 0, arm("flat_tiles", nc=4, vec=1, skips=1, wgs=2), True),       # N % 4 == 0 but 81 wide tiles would fill 2 tasks of 64: two-column tiles
     (3, 64, CA_CB__CA_CB, None, False, 0, 2, arm("one_column"), True),
     (2, 256, N_CA_CB__CB, None, False, 0, 2, arm("one_column"), True),                       # the diagnostic bit
     (1, 50000, CA_CB__CB, (0, 13000), True, 0, 0, arm("one_column"), False),                 # 32-bit store offsets would overflow
@@ -64,7 +67,8 @@ K3_SHAPES = [
     # ---- the reference's order of operations (bit 0 of exact_angles) ----
     (3, 16, CA_CB__CA_CB, None, False, 0, 1, arm("small", nc=16, faithful=1), True),
     (2, 31, CA_CB__CB, None, False, 0, 1, arm("small", nc=32, faithful=1), True),
-    (3, 64, N_CA_CB__CB, None, False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
+    (3, 64, N_CA_CB__CB, None, False, 0, 1, arm("flat_tiles", nc=4, vec=2, skips=1, faithful=1, wgs=2), True),
+    (40, 120, N_CA_CB__CB, (5, 118), True, 0, 1, arm("flat_tiles", nc=4, vec=2, skips=1, faithful=1, wgs=2), True),   # four-column tiles, compact row range
     (700, 62, CA_CB__CB, (3, 50), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
     (700, 50, CA_CB__CB, (3, 50), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
     (300, 90, CA_CB__CA_CB, (3, 90), False, 0, 1, arm("flat_tiles", nc=4, vec=1, skips=1, faithful=1, wgs=2), True),
