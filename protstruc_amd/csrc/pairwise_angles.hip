@@ -1671,6 +1671,30 @@ inline int k3f_go(const K3Go& go, bool exact_sqrt, const K3Shape& sh, dim3 grid,
     return k3_go(go, "featurise", name, sh, k3_featurise<false, NC, VEC, M16, WT, FAITHFUL>, &prep[1], grid, block, dyn, 4u, static_cast<Args&&>(args)...);
 }
 
+// The featuriser sweep's layout for a chain length and float-plane alignment: vector float stores where rows and planes allow
+// (else 64 consecutive floats per store instruction: any N); columns per lane by the lanes a strip wastes
+struct K3fSweepLayout {
+    int nc;
+    bool vec;
+};
+template <bool FAITHFUL>
+inline K3fSweepLayout k3f_sweep_layout(int N, uintptr_t alf) {
+    const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
+    const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
+    // ... or none at all: with the 64-floats-per-store layout the dead column groups of a row's last strip are skipped, so
+    // it computes ceil(N / 64) groups per row pair where the vector layouts compute whole strips (N = 140: 3 against 4,
+    // 342 against 376 us at 2^25 pairs) -- taken where that saves more than the ~15 % its dword stores cost
+    constexpr bool CAN4 = K3_FEATURISE_NC4 && !FAITHFUL;   // (the faithful chains of four columns do not fit 256 VGPRs)
+    const long long gn = (N + 63) / 64, gv = (CAN4 ? std::min(w4, w2) : w2) / 64;
+    const bool prefer_scalar = gn * 115 < gv * 100;
+    int NC = (CAN4 && w4 <= w2) ? 4 : 2;
+    const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
+    // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
+    // 257 / 267; two groups, N = 101: 338 / 310)
+    if (!vec) NC = (CAN4 && (gn > 2 || N <= 64)) ? 4 : 2;   // (N <= 64: one column group, four row pairs per lane -- the 256-VGPR instantiation)
+    return K3fSweepLayout{NC, vec};
+}
+
 template <bool FAITHFUL>
 int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb, float* d_no, float* omega, float* theta, float* phi,
             uint8_t* d_ca_mask, uint8_t* d_cb_mask, uint8_t* d_no_mask, int B, int N, int A, int exact_sqrt, bool simple, uintptr_t alf,
@@ -1690,7 +1714,11 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         const size_t slot_vec4 = (size_t)3 * N + (size_t)6 * n_rp + ((size_t)N + 15) / 16;   // column atoms, row atoms, one byte per residue
         // (odd lengths -- dword and byte stores in the tile kernel -- only below 70 %: N = 129 262 against 339 us, but 101 288 against 272)
         const bool tiles_even = N <= K3F_TILES_MAX_N_EVEN && (long long)N * 100 < (long long)(N % 2 == 0 ? K3F_TILES_UTIL_PERCENT : 70) * 64 * ((N + 63) / 64);
-        if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
+        // ... and even lengths whose sweep would fall back to its 64-floats-per-store layout (three or five column groups: N = 176,
+        // 192, 272 .. 320): the tiles keep their 8-byte stores (192: 222 against 289 us, 288: 216-255 / 318, 320: 232 / 300,
+        // profiles/r05_featuriser_shapes.log)
+        const bool tiles_dword_sweep = N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0 && !k3f_sweep_layout<FAITHFUL>(N, alf).vec;
+        if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even || tiles_dword_sweep) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
             (unsigned long long)N * N < (1ull << 29)) {
             const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(n_rp + 1) / 2;
             const unsigned tps = (TR * TC + 63u) / 64u;
@@ -1733,19 +1761,10 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
     if (!simple && N >= feat_min_n && need <= K3_LDS_MAX && (alf & 3u) == 0 && (unsigned long long)N * N < (1ull << 31)) {
         // vector float stores where rows and planes allow (else 64 consecutive floats per store instruction: any N);
         // columns per lane by the lanes a strip wastes
-        const bool v4 = N % 4 == 0 && (alf & 15u) == 0, v2 = N % 2 == 0 && (alf & 7u) == 0;
-        const long long w4 = (long long)((N + 255) / 256) * 256, w2 = (long long)((N + 127) / 128) * 128;
-        // ... or none at all: with the 64-floats-per-store layout the dead column groups of a row's last strip are skipped, so
-        // it computes ceil(N / 64) groups per row pair where the vector layouts compute whole strips (N = 140: 3 against 4,
-        // 342 against 376 us at 2^25 pairs) -- taken where that saves more than the ~15 % its dword stores cost
-        constexpr bool CAN4 = K3_FEATURISE_NC4 && !FAITHFUL;   // (the faithful chains of four columns do not fit 256 VGPRs)
-        const long long gn = (N + 63) / 64, gv = (CAN4 ? std::min(w4, w2) : w2) / 64;
-        const bool prefer_scalar = gn * 115 < gv * 100;
-        int NC = (CAN4 && w4 <= w2) ? 4 : 2;
-        const bool vec = (NC == 4 ? v4 : v2) && !prefer_scalar;
-        // ... in which four columns per lane beat two from three groups on (same-box A/B: N = 383 234 against 260 us, 301
-        // 257 / 267; two groups, N = 101: 338 / 310)
-        if (!vec) NC = (CAN4 && (gn > 2 || N <= 64)) ? 4 : 2;   // (N <= 64: one column group, four row pairs per lane -- the 256-VGPR instantiation)
+        constexpr bool CAN4 = K3_FEATURISE_NC4 && !FAITHFUL;
+        const K3fSweepLayout lay = k3f_sweep_layout<FAITHFUL>(N, alf);
+        const int NC = lay.nc;
+        const bool vec = lay.vec;
         const bool m16 = vec && N % 16 == 0 && (alm & 15u) == 0;   // strip-local 16-byte mask stores: whole 16-column groups
         // write-through where strips are whole and every store covers whole lines; same-box A/B, trace: N = 512 174 against 178 us,
         // 256 181 / 187 -- but N = 480 (15 lines per row, a 224-column second strip) 239 against 212 and 160 308 / 297: there write-back

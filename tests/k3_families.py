@@ -108,6 +108,9 @@ FEATURISER_SHAPES = [
     (3, 48, 4, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=3, wt=0, wgs=2), True),
     (2, 160, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # even N, 83 % of a sweep's lanes
     (2, 200, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),
+    (2, 192, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # three column groups: the sweep would write dwords
+    (2, 300, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # five column groups
+    (2, 288, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
     (3, 48, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
     (700, 64, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
     (3, 80, 4, 3, 1, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, faithful=1, wgs=2), True),

@@ -64,7 +64,7 @@ def test_the_tables_cover_every_arm_the_dispatchers_report():
     assert seen <= have, sorted(seen - have)
     fhave = {arm_key(_feat(e)[0], FEATURISER_ARM_KEYS) for e in FEATURISER_SHAPES}
     fseen = set()
-    for N in (5, 8, 33, 48, 63, 64, 70, 80, 96, 97, 100, 101, 110, 111, 112, 128, 129, 140, 160, 200, 255, 256, 258, 300, 301, 383, 384, 480, 496, 500, 511, 512, 516, 1030, 2048, 2100):
+    for N in (5, 8, 33, 48, 63, 64, 70, 80, 96, 97, 100, 101, 110, 111, 112, 128, 129, 140, 160, 176, 192, 200, 255, 256, 258, 272, 288, 300, 301, 320, 336, 383, 384, 480, 496, 500, 511, 512, 516, 1030, 2048, 2100):
         for B in (1, 3, 600, 1024, 3000):
             for fmis, mmis in ((0, 0), (4, 0), (8, 0), (0, 5), (16, 16), (64, 0), (4, 3)):
                 for mode in (0, 1, 2, 3):
