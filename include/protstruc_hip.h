@@ -234,9 +234,9 @@ typedef struct ps_k3_plan {
     int columns_per_lane;       /* sweep / featurise: 2 or 4 column residues per lane; flat_tiles: chains per lane (a 2 x 2 tile);
                                    small: the padded chain length (16 / 32); else 1 */
     int vector_stores;          /* 1: the lane's columns are adjacent (8- / 16-byte stores); 0: 64 apart / dword stores (any N);
-                                   flat_tiles: 2 = four-column tiles, 16-byte stores (N % 4 == 0), 1 = two-column tiles, 8-byte stores */
+                                   flat_tiles / featurise_tiles: 2 = four-column tiles, 16-byte stores (N % 4 == 0), 1 = two-column tiles, 8-byte stores */
     int skips_dead_groups;      /* 1: dead 64-column groups of a row's last strip are not evaluated */
-    int mask_store_mode;        /* featuriser: 3 two bytes per tile row (tiles), 2 strip-local 16-byte stores, 1 flat 16-byte stores, 0 bytes */
+    int mask_store_mode;        /* featuriser: 4 four bytes / 3 two bytes per tile row (tiles), 2 strip-local 16-byte stores, 1 flat 16-byte stores, 0 bytes */
     int write_through;          /* featuriser: sc1 stores */
     int faithful;               /* bit 0 of exact_angles */
     int rows_per_task;          /* rows of one pulled task (sweep / featurise); rows per workgroup otherwise */

@@ -1120,8 +1120,8 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
     const float* __restrict__ xyz, const uint8_t* __restrict__ amask, float* __restrict__ d_ca,
     float* __restrict__ d_cb, float* __restrict__ d_no, float* __restrict__ omega, float* __restrict__ theta,
     float* __restrict__ phi, uint8_t* __restrict__ m_ca, uint8_t* __restrict__ m_cb, uint8_t* __restrict__ m_no, int N,
-    int A, int KS, unsigned tps, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, unsigned rcpTC, int slot_vec4, int vec2f,
-    int vec2m) {
+    int A, int KS, unsigned tps, unsigned n_tasks, unsigned tasks_per_wg, unsigned rcpN, unsigned rcpTC, int slot_vec4, int vecf,
+    int vecm) {
     // [slot]: column atoms CA, O, CB as {x, y, z, -} per (atom, residue): 3 N vec4; row atoms N, CA, CB pair-interleaved
     // {x0, x1, y0, y1}, {z0, z1, -, -} per (row pair, atom): 6 RP vec4; then one byte per residue: bits 0..2 = row side
     // (N, CA, CB present), bits 4..6 = column side (CA, CB, O present)
@@ -1134,7 +1134,9 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
     if (t0 >= t1) return;                         // whole workgroup
     const int n_rp = (N + 1) >> 1;
     const int col_vec4 = 3 * N, row_vec4 = 6 * n_rp;
-    const unsigned TC = (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
+    // tiles of two row pairs x two columns -- or four (vecf == 4: N % 4 == 0, 16-byte float rows, 4-byte mask rows)
+    const bool wide = vecf == 4;                  // (uniform)
+    const unsigned TC = wide ? (unsigned)N >> 2 : (unsigned)(N + 1) >> 1, TR = (unsigned)(n_rp + 1) >> 1, FT = TR * TC;
     const unsigned b_first = t0 / tps, b_last = (t1 - 1u) / tps;
     K3F_STAMP(0);
     [[maybe_unused]] int pass = 0;
@@ -1188,21 +1190,15 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
             const unsigned tcl = min(ti, FT - 1u);
             unsigned tr = __umulhi(tcl, rcpTC), tc = tcl - tr * TC;
             if (tc >= TC) ++tr, tc -= TC;
-            const int c0 = (int)(2u * tc), c1 = min(c0 + 1, N - 1);
+            const int c0 = (int)(wide ? 4u * tc : 2u * tc);
             const int rpA = (int)(2u * tr), rpB = min(rpA + 1, n_rp - 1);
             const bool lc1 = c0 + 1 < N, lrB = rpA + 1 < n_rp;
             // rows 2 rpA (always there), 2 rpA + 1, 2 rpB, 2 rpB + 1
             const int iA0 = 2 * rpA, iA1 = min(iA0 + 1, N - 1), iB0 = 2 * rpB, iB1 = min(iB0 + 1, N - 1);
             const bool rA1 = iA0 + 1 < N, rB0 = lrB, rB1 = lrB && iB0 + 1 < N;
-            f3v NV[4], CAV[4], CBV[4], CAJ[4], CBJ[4], OJ[4];
+            // chain c of a half: row pair A (c = 0, 1) or B (2, 3) x the half's first / second column; .x / .y = the pair's rows
+            f3v NV[4], CAV[4], CBV[4], CAJ[2][4], CBJ[2][4], OJ[2][4];
             {
-                const k3_f32x4 ca0 = slot[c0], ca1 = slot[c1], o0 = slot[N + c0], o1 = slot[N + c1], cb0 = slot[2 * N + c0], cb1 = slot[2 * N + c1];
-                CAJ[0] = CAJ[2] = mk3v(f3{ca0.x, ca0.y, ca0.z}, f3{ca0.x, ca0.y, ca0.z});
-                CAJ[1] = CAJ[3] = mk3v(f3{ca1.x, ca1.y, ca1.z}, f3{ca1.x, ca1.y, ca1.z});
-                OJ[0] = OJ[2] = mk3v(f3{o0.x, o0.y, o0.z}, f3{o0.x, o0.y, o0.z});
-                OJ[1] = OJ[3] = mk3v(f3{o1.x, o1.y, o1.z}, f3{o1.x, o1.y, o1.z});
-                CBJ[0] = CBJ[2] = mk3v(f3{cb0.x, cb0.y, cb0.z}, f3{cb0.x, cb0.y, cb0.z});
-                CBJ[1] = CBJ[3] = mk3v(f3{cb1.x, cb1.y, cb1.z}, f3{cb1.x, cb1.y, cb1.z});
                 auto row_atom = [&](int rp, int q) {
                     const k3_f32x4 xy = rowp[(rp * 3 + q) * 2];
                     const f32x2 z = *reinterpret_cast<const f32x2*>(rowp + (rp * 3 + q) * 2 + 1);
@@ -1210,15 +1206,37 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
                 };
                 NV[0] = NV[1] = row_atom(rpA, 0); CAV[0] = CAV[1] = row_atom(rpA, 1); CBV[0] = CBV[1] = row_atom(rpA, 2);
                 NV[2] = NV[3] = row_atom(rpB, 0); CAV[2] = CAV[3] = row_atom(rpB, 1); CBV[2] = CBV[3] = row_atom(rpB, 2);
+                auto cols = [&](int ca, f3v (&CA)[4], f3v (&CB)[4], f3v (&O)[4]) {
+                    const int cb = min(ca + 1, N - 1);            // clamped: a dead column is never stored
+                    const k3_f32x4 ca0 = slot[ca], ca1 = slot[cb], o0 = slot[N + ca], o1 = slot[N + cb], cb0 = slot[2 * N + ca], cb1 = slot[2 * N + cb];
+                    CA[0] = CA[2] = mk3v(f3{ca0.x, ca0.y, ca0.z}, f3{ca0.x, ca0.y, ca0.z});
+                    CA[1] = CA[3] = mk3v(f3{ca1.x, ca1.y, ca1.z}, f3{ca1.x, ca1.y, ca1.z});
+                    O[0] = O[2] = mk3v(f3{o0.x, o0.y, o0.z}, f3{o0.x, o0.y, o0.z});
+                    O[1] = O[3] = mk3v(f3{o1.x, o1.y, o1.z}, f3{o1.x, o1.y, o1.z});
+                    CB[0] = CB[2] = mk3v(f3{cb0.x, cb0.y, cb0.z}, f3{cb0.x, cb0.y, cb0.z});
+                    CB[1] = CB[3] = mk3v(f3{cb1.x, cb1.y, cb1.z}, f3{cb1.x, cb1.y, cb1.z});
+                };
+                cols(c0, CAJ[0], CBJ[0], OJ[0]);
+                cols(wide ? c0 + 2 : c0, CAJ[1], CBJ[1], OJ[1]);   // (the second half exists only in a four-column tile)
             }
             constexpr int DEAD = 0x7FFFFFF0;    // beyond num_records: dropped by the range check
             const int offA = (int)__umul24((unsigned)iA0, (unsigned)N) + c0, offB = (int)__umul24((unsigned)iB0, (unsigned)N) + c0;   // in elements
             const bool l1 = lt && lc1;
-            // one plane's four chains: {v[0], v[1]} = row pair A x columns c0, c1; {v[2], v[3]} = row pair B; .x / .y = the pair's rows
-            auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[4]) {
+            // one plane's chains: v = the tile's first two columns, w = its third and fourth (four-column tiles only)
+            auto emit = [&](const __amdgpu_buffer_rsrc_t& rr, f32x2 (&v)[4], f32x2 (&w)[4]) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(v[c]));
-                if (vec2f) {     // (uniform)
+                if (wide) {      // (uniform) a row of the tile is one 16-byte store
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(w[c]));
+                    auto st4 = [&](float a, float b, float c, float d, int off) {
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(k3_u32x4, k3_f32x4{a, b, c, d}), rr, off, 0, 0);
+                    };
+                    st4(v[0].x, v[1].x, w[0].x, w[1].x, lt ? offA * 4 : DEAD);
+                    st4(v[0].y, v[1].y, w[0].y, w[1].y, (lt && rA1) ? (offA + N) * 4 : DEAD);
+                    st4(v[2].x, v[3].x, w[2].x, w[3].x, (lt && rB0) ? offB * 4 : DEAD);
+                    st4(v[2].y, v[3].y, w[2].y, w[3].y, (lt && rB1) ? (offB + N) * 4 : DEAD);
+                } else if (vecf == 2) {
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].x, v[1].x}), rr, lt ? offA * 4 : DEAD, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[0].y, v[1].y}), rr, (lt && rA1) ? (offA + N) * 4 : DEAD, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(k3_u32x2, f32x2{v[2].x, v[3].x}), rr, (lt && rB0) ? offB * 4 : DEAD, 0, 0);
@@ -1236,11 +1254,19 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
             };
             // the three mask planes first (their stores drain while the arithmetic runs): rows' bits 0..2 = N, CA, CB; columns' bits 4..6 = CA, CB, O
             {
-                const unsigned mA0 = mbits[iA0], mA1 = mbits[iA1], mB0 = mbits[iB0], mB1 = mbits[iB1], mc0 = mbits[c0] >> 4, mc1 = mbits[c1] >> 4;
+                const unsigned mA0 = mbits[iA0], mA1 = mbits[iA1], mB0 = mbits[iB0], mB1 = mbits[iB1];
+                const unsigned mc0 = mbits[c0] >> 4, mc1 = mbits[min(c0 + 1, N - 1)] >> 4;
+                const unsigned mc2 = mbits[min(c0 + 2, N - 1)] >> 4, mc3 = mbits[min(c0 + 3, N - 1)] >> 4;   // (four-column tiles)
                 auto plane = [&](const __amdgpu_buffer_rsrc_t& rr, unsigned rbit, unsigned cbit) {
                     const unsigned k0 = (mc0 >> cbit) & 1u, k1 = (mc1 >> cbit) & 1u;
                     const unsigned a0 = (mA0 >> rbit) & 1u, a1 = (mA1 >> rbit) & 1u, b0 = (mB0 >> rbit) & 1u, b1 = (mB1 >> rbit) & 1u;
-                    if (vec2m) {     // (uniform) two bytes per row of the tile
+                    if (wide) {      // (uniform) four bytes per row of the tile
+                        const unsigned kk = k0 | (k1 << 8) | (((mc2 >> cbit) & 1u) << 16) | (((mc3 >> cbit) & 1u) << 24);
+                        __builtin_amdgcn_raw_buffer_store_b32(a0 ? kk : 0u, rr, lt ? offA : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(a1 ? kk : 0u, rr, (lt && rA1) ? offA + N : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(b0 ? kk : 0u, rr, (lt && rB0) ? offB : DEAD, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(b1 ? kk : 0u, rr, (lt && rB1) ? offB + N : DEAD, 0, 0);
+                    } else if (vecm == 2) {     // (uniform) two bytes per row of the tile
                         const unsigned kk = k0 | (k1 << 8);
                         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(a0 ? kk : 0u), rr, lt ? offA : DEAD, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(a1 ? kk : 0u), rr, (lt && rA1) ? offA + N : DEAD, 0, 0);
@@ -1261,32 +1287,32 @@ __global__ __launch_bounds__(512) void k3_featurise_tiles(
                 plane(r_mcb, 2u, 1u);      // CB_i & CB_j
                 plane(r_mno, 0u, 2u);      // N_i & O_j
             }
-            f32x2 v[4];
+            f32x2 v[4], w[4];
 #ifdef PS_K3_AB
             const int probe = k3f_probe;
             if (probe == 1) {
-                for (int c = 0; c < 4; ++c) v[c] = f32x2{(float)lane, (float)c};
-                emit(r_dca, v); emit(r_dcb, v); emit(r_dno, v); emit(r_ph, v); emit(r_om, v); emit(r_th, v);
+                for (int c = 0; c < 4; ++c) v[c] = w[c] = f32x2{(float)lane, (float)c};
+                emit(r_dca, v, w); emit(r_dcb, v, w); emit(r_dno, v, w); emit(r_ph, v, w); emit(r_om, v, w); emit(r_th, v, w);
             } else {
 #endif
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(CAV[c], CAJ[c]);
-            emit(r_dca, v);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(CBV[c], CBJ[c]);
-            emit(r_dcb, v);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = dist3v_t<EXACT>(NV[c], OJ[c]);
-            emit(r_dno, v);
-            if constexpr (FAITHFUL) angle3v_ref_n<4>(CAV, CBV, CBJ, v);
-            else angle3v_n<4>(CAV, CBV, CBJ, v);
-            emit(r_ph, v);
-            if constexpr (FAITHFUL) dihedral4v_ref_n<4>(CAV, CBV, CAJ, CBJ, v);      // as coded at protstruc.py:811
-            else dihedral4v_k3_n<4>(CAV, CBV, CAJ, CBJ, v);
-            emit(r_om, v);
-            if constexpr (FAITHFUL) dihedral4v_ref_n<4>(NV, CAV, CBV, CBJ, v);
-            else dihedral4v_k3_n<4>(NV, CAV, CBV, CBJ, v);
-            emit(r_th, v);
+            // each plane: the first half's four chains, the second half's (four-column tiles), the stores
+#define K3F_TILE_PLANE(RSRC, EXPR0, EXPR1)      \
+            { EXPR0; if (wide) { EXPR1; } emit(RSRC, v, w); }
+#define K3F_DIST(R, C, OUT) _Pragma("unroll") for (int c = 0; c < 4; ++c) OUT[c] = dist3v_t<EXACT>(R[c], C[c])
+            K3F_TILE_PLANE(r_dca, K3F_DIST(CAV, CAJ[0], v), K3F_DIST(CAV, CAJ[1], w))
+            K3F_TILE_PLANE(r_dcb, K3F_DIST(CBV, CBJ[0], v), K3F_DIST(CBV, CBJ[1], w))
+            K3F_TILE_PLANE(r_dno, K3F_DIST(NV, OJ[0], v), K3F_DIST(NV, OJ[1], w))
+            if constexpr (FAITHFUL) {
+                K3F_TILE_PLANE(r_ph, angle3v_ref_n<4>(CAV, CBV, CBJ[0], v), angle3v_ref_n<4>(CAV, CBV, CBJ[1], w))
+                K3F_TILE_PLANE(r_om, dihedral4v_ref_n<4>(CAV, CBV, CAJ[0], CBJ[0], v), dihedral4v_ref_n<4>(CAV, CBV, CAJ[1], CBJ[1], w))   // as coded at protstruc.py:811
+                K3F_TILE_PLANE(r_th, dihedral4v_ref_n<4>(NV, CAV, CBV, CBJ[0], v), dihedral4v_ref_n<4>(NV, CAV, CBV, CBJ[1], w))
+            } else {
+                K3F_TILE_PLANE(r_ph, angle3v_n<4>(CAV, CBV, CBJ[0], v), angle3v_n<4>(CAV, CBV, CBJ[1], w))
+                K3F_TILE_PLANE(r_om, dihedral4v_k3_n<4>(CAV, CBV, CAJ[0], CBJ[0], v), dihedral4v_k3_n<4>(CAV, CBV, CAJ[1], CBJ[1], w))
+                K3F_TILE_PLANE(r_th, dihedral4v_k3_n<4>(NV, CAV, CBV, CBJ[0], v), dihedral4v_k3_n<4>(NV, CAV, CBV, CBJ[1], w))
+            }
+#undef K3F_DIST
+#undef K3F_TILE_PLANE
 #ifdef PS_K3_AB
             }
 #endif
@@ -1720,7 +1746,21 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         const bool tiles_dword_sweep = N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0 && !k3f_sweep_layout<FAITHFUL>(N, alf).vec;
         if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even || tiles_dword_sweep) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
             (unsigned long long)N * N < (1ull << 29)) {
-            const unsigned TC = (unsigned)(N + 1) / 2, TR = (unsigned)(n_rp + 1) / 2;
+            // four-column tiles where a row of the tile is one 16-byte float store and one 4-byte mask store -- unless a structure's
+            // wide tiles would idle > 8 % more lanes of their last task of 64 (as in launch_flat)
+            const unsigned TR = (unsigned)(n_rp + 1) / 2;
+            int vecf = (N % 2 == 0 && (alf & 7u) == 0) ? 2 : 0, vecm = (N % 2 == 0 && (alm & 1u) == 0) ? 2 : 0;
+#ifdef PS_K3_AB
+            static const int tiles_wide = getenv("PS_K3F_TILES_WIDE") ? atoi(getenv("PS_K3F_TILES_WIDE")) : 1;
+#else
+            constexpr int tiles_wide = 1;
+#endif
+            if (tiles_wide && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0) {
+                const unsigned ft_w = TR * ((unsigned)N / 4), ft_n = TR * ((unsigned)N / 2);
+                const unsigned long long lanes_w = 64ull * ((ft_w + 63) / 64) * 2, lanes_n = 64ull * ((ft_n + 63) / 64);
+                if (lanes_w * 100 <= lanes_n * 108) vecf = vecm = 4;
+            }
+            const unsigned TC = vecf == 4 ? (unsigned)N / 4 : (unsigned)(N + 1) / 2;
             const unsigned tps = (TR * TC + 63u) / 64u;
             const unsigned long long n_tasks = (unsigned long long)tps * B;
             if (n_tasks > 0x7FFFFFFFull) return (int)hipErrorInvalidValue;
@@ -1737,17 +1777,16 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
             const unsigned grid = (unsigned)((n_tasks + tasks_per_wg - 1) / tasks_per_wg);
             const unsigned share = (tasks_per_wg + tps - 1) / tps + 1;
             const int KS = (int)std::max<size_t>(1, std::min<size_t>(tiles_lds / (slot_vec4 * 16), (share + 3) / 4));
-            const int vec2f = N % 2 == 0 && (alf & 7u) == 0, vec2m = N % 2 == 0 && (alm & 1u) == 0;
             char name[96];
             snprintf(name, sizeof name, "k3_featurise_tiles<EXACT=%d,FAITHFUL=%d>", exact_sqrt, (int)FAITHFUL);
             K3Shape sh;
-            sh.nc = 4; sh.vec = vec2f; sh.skips = 1; sh.mask_mode = vec2m ? 3 : 0; sh.faithful = FAITHFUL; sh.wgs_per_cu = (int)tiles_wgs; sh.structs_per_segment = KS;
+            sh.nc = 4; sh.vec = vecf / 2; sh.skips = 1; sh.mask_mode = vecm == 4 ? 4 : vecm == 2 ? 3 : 0; sh.faithful = FAITHFUL; sh.wgs_per_cu = (int)tiles_wgs; sh.structs_per_segment = KS;
             sh.n_tasks = (unsigned)n_tasks; sh.tasks_per_wg = tasks_per_wg;
             static unsigned long long prep[2][1] = {{0}, {0}};
             auto tiles = [&](auto kernel, unsigned long long (&prepared)[1]) {
                 return k3_go(go, "featurise_tiles", name, sh, kernel, &prepared, dim3(grid), dim3(256), tiles_lds, 4u, xyz, atom_mask, d_ca, d_cb,
                              d_no, omega, theta, phi, d_ca_mask, d_cb_mask, d_no_mask, N, A, KS, tps, (unsigned)n_tasks, tasks_per_wg,
-                             (unsigned)((1ull << 32) / (unsigned)N), (unsigned)((1ull << 32) / std::max(1u, TC)), (int)slot_vec4, vec2f, vec2m);
+                             (unsigned)((1ull << 32) / (unsigned)N), (unsigned)((1ull << 32) / std::max(1u, TC)), (int)slot_vec4, vecf, vecm);
             };
             return exact_sqrt ? tiles(k3_featurise_tiles<true, FAITHFUL>, prep[0]) : tiles(k3_featurise_tiles<false, FAITHFUL>, prep[1]);
         }

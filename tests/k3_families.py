@@ -101,18 +101,18 @@ FEATURISER_SHAPES = [
     (3, 5, 0, 0, 1, farm("one_column", faithful=1), True),
     (2, 256, 0, 0, 3, farm("one_column", faithful=1), True),
     (3, 48, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # 8-byte float stores, 2-byte mask stores
-    (700, 64, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # several staging passes per workgroup
+    (700, 64, 0, 0, 0, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, wgs=2), True),   # several staging passes per workgroup
     (3, 33, 0, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, wgs=2), True),   # odd N: dword and byte stores
     (3, 80, 4, 3, 0, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, wgs=2), True),   # planes on 4-byte / odd boundaries
     (3, 48, 0, 5, 0, farm("featurise_tiles", nc=4, vec=1, mask=0, wt=0, wgs=2), True),
     (3, 48, 4, 0, 0, farm("featurise_tiles", nc=4, vec=0, mask=3, wt=0, wgs=2), True),
-    (2, 160, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # even N, 83 % of a sweep's lanes
-    (2, 200, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),
-    (2, 192, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # three column groups: the sweep would write dwords
-    (2, 300, 0, 0, 0, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, wgs=2), True),   # five column groups
-    (2, 288, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
+    (2, 160, 0, 0, 0, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, wgs=2), True),   # even N, 83 % of a sweep's lanes
+    (2, 200, 0, 0, 0, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, wgs=2), True),
+    (2, 192, 0, 0, 0, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, wgs=2), True),   # three column groups: the sweep would write dwords
+    (2, 300, 0, 0, 0, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, wgs=2), True),   # five column groups
+    (2, 288, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
     (3, 48, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
-    (700, 64, 0, 0, 1, farm("featurise_tiles", nc=4, vec=1, mask=3, wt=0, faithful=1, wgs=2), True),
+    (700, 64, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
     (3, 80, 4, 3, 1, farm("featurise_tiles", nc=4, vec=0, mask=0, wt=0, faithful=1, wgs=2), True),
     (3, 48, 0, 5, 1, farm("featurise_tiles", nc=4, vec=1, mask=0, wt=0, faithful=1, wgs=2), True),
     (3, 60, 4, 0, 1, farm("featurise_tiles", nc=4, vec=0, mask=3, wt=0, faithful=1, wgs=2), True),
