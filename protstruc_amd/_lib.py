@@ -239,8 +239,9 @@ def _k3_plan_dict(plan):
 
 def k3_plan(B, N, A, slots_i, slots_j, n_points, row_begin=0, row_end=None, *, compact=False, out_misalign=0, exact_angles=0,
             cu_count=0):
-    """Which kernel ``ps_pairwise_angles_f32`` takes for this launch: a dict with ``family`` ("sweep", "small",
-    "one_column", "empty"), ``kernel`` (name with template arguments), the layout (``columns_per_lane``, ``vector_stores``,
+    """Which kernel ``ps_pairwise_angles_f32`` takes for this launch: a dict with ``family`` ("sweep", "flat_tiles",
+    "small", "one_column", "empty"), ``kernel`` (name with template arguments), the layout (``columns_per_lane``,
+    ``vector_stores`` -- flat_tiles: 2 = four-column tiles with 16-byte rows, 1 = two-column tiles, 0 = dword stores --,
     ``skips_dead_groups``, ``faithful``), ``rows_per_task``, ``workgroups_per_cu``, grid, workgroup size and LDS bytes.
     Pure host query (``ps_k3_plan_f32``): the library runs its own dispatcher in record-only mode; no GPU needed.
     ``cu_count`` <= 0 means 256 (MI355X)."""
