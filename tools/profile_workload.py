@@ -59,7 +59,7 @@ if what in ("k3", "k3p"):
         repeat(lambda: sb.pairwise_planar_angles(["CA", "CB"], ["CB"]))
         repeat(lambda: sb.inter_residue_geometry())
     ops.set_exact_angles(False)
-elif what == "k3flat":      # the flat K3 kernel at 2^25 pairs: N = 64 (column-per-lane map), 99 and 48 (64-apart map), N = 512 (the sweep) beside it
+elif what == "k3flat":      # the tile K3 kernel at 2^25 pairs: N = 64 (four-column tiles), 99 and 48 (two-column tiles), N = 512 (the sweep) beside it
     for n in (64, 99, 48, 512):
         b = (1 << 25) // (n * n)
         xyz, _ = synth(b, n)
