@@ -704,14 +704,61 @@ def other_configs(dev, steps):
                               "coordinates <= 1e-5 (<= 1e-3 of entries beyond); masked mean / variance of the final coordinates ~ (0, 1)",
                 "cpu_oracle_backbone_orientations_us_4_structures": cpu_s * 1e6}
 
+    # ---- not a BASELINE config: K3 and the featuriser away from N = 512 (2^25 pairs per launch: the tile kernels' lengths) ----
+    def chain_lengths():
+        res = {"workload": "2^25 residue pairs per launch at N = 64, 192 and 320 (the lengths of the tile kernels): the (2,2) dihedral, 4 B "
+                           "per pair, and the fused featuriser, 27 B per pair; fast arithmetic; host-paced HIP events",
+               "check_what": "3 structures of each timed output vs the CPU oracle: dihedral <= 1e-4 of off-diagonal entries beyond 1e-5; "
+                             "featuriser omega bit-identical to that launch, CA-CA distances <= 1e-5, mask plane exact"}
+        for n in (64, 192, 320):
+            b = (1 << 25) // (n * n)
+            xyz_c, mask_c = synth(10 + n, b, n)
+            xyz = xyz_c.to(dev)
+            sb = StructureBatch.from_xyz(xyz_c, mask_c, device=dev)
+            pick = [0, b // 2, b - 1]
+            outbuf = torch.full((b, n, n), float("inf"), device=dev)
+            fn = lambda: ops.pairwise_angles(xyz, [1, 4], [1, 4], 4, out=outbuf)
+            ts = _event_times_us(fn, max(5, steps // 2))
+            got = outbuf[pick].cpu()
+            ref = O.pairwise_dihedrals(xyz_c[pick], [1, 4], [1, 4])
+            off = ~torch.eye(n, dtype=torch.bool).expand(len(pick), n, n)
+            both = off & ~torch.isnan(ref) & ~torch.isnan(got)
+            frac_bad = ((got - ref).abs()[both] > 1e-5).float().mean().item()
+            ok = frac_bad <= 1e-4 and not torch.isinf(outbuf).any().item()
+            plan = _lib.k3_plan(b, n, N_ATOM, [1, 4], [1, 4], 4, out_misalign=outbuf.data_ptr() % 16, cu_count=cus)
+            us = sum(ts) / len(ts)
+            leg = {"B": b, "dihedral_CA_CB__CA_CB": {"kernel": plan["kernel"], "family": plan["family"], "us": us, "us_min_max": [min(ts), max(ts)],
+                                                     "G_pairs_per_s": b * n * n / us / 1e3,
+                                                     "check": "ok" if ok else f"frac beyond 1e-5: {frac_bad:.2e}"}}
+            ts = _event_times_us(lambda: sb.inter_residue_geometry(), max(5, steps // 2))
+            geo = sb.inter_residue_geometry()
+            ca = xyz_c[pick][:, :, 1]
+            want = (ca[:, :, None] - ca[:, None, :]).square().sum(-1).sqrt()
+            mk = mask_c[pick][:, :, 1]
+            ok = (torch.equal(geo["omega"].isnan(), outbuf.isnan()) and torch.equal(geo["omega"].nan_to_num(0), outbuf.nan_to_num(0))
+                  and (geo["d_ca"][pick].cpu() - want).abs().max().item() <= 1e-5
+                  and torch.equal(geo["d_ca_mask"][pick].cpu().bool(), mk[:, :, None] & mk[:, None, :]))
+            plan = _lib.featuriser_plan(b, n, N_ATOM, exact_sqrt=_lib.get_tuning("k1_exact_sqrt", dev), cu_count=cus)
+            us = sum(ts) / len(ts)
+            leg["inter_residue_geometry"] = {"kernel": plan["kernel"], "family": plan["family"], "us": us, "us_min_max": [min(ts), max(ts)],
+                                             "G_pairs_per_s": b * n * n / us / 1e3,
+                                             "frac_of_hbm_peak": b * n * n * 27 / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                                             "check": "ok" if ok else "a plane differs from its K3 launch / the distance formula / the mask"}
+            res[f"N={n}"] = leg
+            del outbuf, geo, sb, xyz
+            torch.cuda.empty_cache()
+        return res
+
     guarded("config2", config2)
     torch.cuda.empty_cache()
     guarded("config3", config3)
     torch.cuda.empty_cache()
     guarded("config5", config5)
     torch.cuda.empty_cache()
+    guarded("chain_lengths", chain_lengths)
+    torch.cuda.empty_cache()
     checks = []
-    for cname in ("config2", "config3", "config5"):
+    for cname in ("config2", "config3", "config5", "chain_lengths"):
         def walk(o):
             if isinstance(o, dict):
                 if "error" in o:
