@@ -1744,7 +1744,10 @@ int k3f_run(const float* xyz, const uint8_t* atom_mask, float* d_ca, float* d_cb
         // 192, 272 .. 320): the tiles keep their 8-byte stores (192: 222 against 289 us, 288: 216-255 / 318, 320: 232 / 300,
         // profiles/r05_featuriser_shapes.log)
         const bool tiles_dword_sweep = N % 2 == 0 && (alf & 7u) == 0 && (alm & 1u) == 0 && !k3f_sweep_layout<FAITHFUL>(N, alf).vec;
-        if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even || tiles_dword_sweep) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
+        // ... and, in the faithful arithmetic (whose sweep has two columns per lane), every length with four-column tiles: level
+        // with the sweep at 192 / 256 / 320 / 384, 5-12 % faster at 128, 224, 352, 448-500 (profiles/r05_featuriser_tile_width.log)
+        const bool tiles_faithful = FAITHFUL && N % 4 == 0 && (alf & 15u) == 0 && (alm & 3u) == 0;
+        if (!simple && N >= tiles_min && (N <= tiles_max || tiles_even || tiles_dword_sweep || tiles_faithful) && (alf & 3u) == 0 && slot_vec4 * 16 <= 48 * 1024 &&
             (unsigned long long)N * N < (1ull << 29)) {
             // four-column tiles where a row of the tile is one 16-byte float store and one 4-byte mask store -- unless a structure's
             // wide tiles would idle > 8 % more lanes of their last task of 64 (as in launch_flat)

@@ -137,13 +137,17 @@ FEATURISER_SHAPES = [
     (1024, 110, 0, 0, 0, farm("featurise", nc=2, vec=1, mask=1, wt=0, wgs=2), True),
     (1024, 101, 0, 0, 0, farm("featurise", nc=2, vec=0, mask=1, wt=0, wgs=2), True),
     (2, 512, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=1), True),
-    (2, 496, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=1), True),
-    (2, 500, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, wt=0, faithful=1, wgs=1), True),
+    (2, 496, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
+    (2, 500, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
     (2, 301, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, wt=0, faithful=1, wgs=1), True),
-    (1024, 128, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=2), True),
-    (1024, 112, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=2), True),
+    (1024, 128, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
+    (1024, 112, 0, 0, 1, farm("featurise_tiles", nc=4, vec=2, mask=4, wt=0, faithful=1, wgs=2), True),
     (1024, 110, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, wt=0, faithful=1, wgs=2), True),
     (1024, 101, 0, 0, 1, farm("featurise", nc=2, vec=0, mask=1, wt=0, faithful=1, wgs=2), True),
+    (2, 498, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=1, wt=0, faithful=1, wgs=1), True),   # faithful sweep (no four-column tiles here)
+    (1100, 128, 8, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=2), True),   # faithful sweep (no four-column tiles here)
+    (2, 112, 8, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=0, faithful=1, wgs=1), True),   # faithful sweep: planes 8-byte aligned only
+    (1024, 512, 0, 0, 1, farm("featurise", nc=2, vec=1, mask=2, wt=1, faithful=1, wgs=2), False),   # (config-3 length in a large batch: plan only, 27 GB of planes)
 ]
 
 

@@ -1,14 +1,17 @@
 #!/usr/bin/python3
 """The fused featuriser (inter_residue_geometry) against the padded length: us per launch (median / min of `reps`, one HIP-event
 pair per launch, host-paced) at a fixed number of residue pairs (2^25, BASELINE config 3's), and the rate in G pairs/s.
-python3 tools/k3_featuriser_shapes.py [reps] [N ...]"""
+python3 tools/k3_featuriser_shapes.py [reps] [N ...]      (PS_K3_FAITHFUL=1: the reference's order of operations)"""
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
-from protstruc_amd import StructureBatch
+from protstruc_amd import StructureBatch, ops
+
+if os.environ.get("PS_K3_FAITHFUL"):
+    ops.set_exact_angles(True)
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 lengths = [int(v) for v in sys.argv[2:]] or [512, 511, 510, 500, 384, 383, 256, 255, 200, 129, 128, 101, 100, 99, 64]
